@@ -1,0 +1,388 @@
+/*
+ * bh_oracle.c -- CPU oracle for the Barnes-Hut step.  TEST INFRASTRUCTURE ONLY.
+ * See bh_oracle.h for the rules on who may load this and for the parity status (pinned).
+ *
+ * Every function restates, in plain C, the arithmetic of the reference function it
+ * cites, operation for operation and in the same order, so that fp64 results are
+ * bit-identical to the reference compiled without FMA contraction (x86-64 g++ -O2).
+ * Build with -ffp-contract=off.
+ */
+#include "bh_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define BHO_UNCAPPED_LIMIT 200
+
+/* ---- root box: project.cu:536-573 ------------------------------------------------- */
+void bho_root_bounds(const double *pos, int64_t n, double out[4])
+{
+    double xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
+    for (int64_t i = 0; i < n; ++i) {
+        double x = pos[2 * i], y = pos[2 * i + 1];
+        /* std::min(a,b) = (b<a)?b:a ; std::max(a,b) = (a<b)?b:a */
+        xlo = (x < xlo) ? x : xlo;
+        xhi = (xhi < x) ? x : xhi;
+        ylo = (y < ylo) ? y : ylo;
+        yhi = (yhi < y) ? y : yhi;
+    }
+    double ex = xhi - xlo, ey = yhi - ylo;
+    double span = (ex < ey) ? ey : ex;
+    double pad = 0.1 * span;
+    if (span == 0.0) pad = 1e-6;
+    out[0] = xlo - pad;
+    out[1] = xhi + pad;
+    out[2] = ylo - pad;
+    out[3] = yhi + pad;
+}
+
+/* ---- insertion: project.cu:343-453 / main_approach_2.cpp:73-144 -------------------- */
+typedef struct {
+    bho_node *nodes;
+    int64_t count, cap;
+    const double *pos, *mass;
+    int max_depth; /* <=0: uncapped */
+    int err;
+} build_ctx;
+
+static void blank_node(bho_node *q, double x0, double x1, double y0, double y1)
+{
+    q->child[0] = q->child[1] = q->child[2] = q->child[3] = -1;
+    q->comx = q->comy = q->mass = 0.0;
+    q->xmin = x0; q->xmax = x1; q->ymin = y0; q->ymax = y1;
+    q->particle = -1;
+}
+
+/* project.cu:348-356 */
+static int pick_child(double x, double y, const bho_node *q)
+{
+    double mx = (q->xmin + q->xmax) / 2;
+    double my = (q->ymin + q->ymax) / 2;
+    if (x <  mx && y <  my) return 0;
+    if (x >= mx && y <  my) return 1;
+    if (x <  mx && y >= my) return 2;
+    return 3;
+}
+
+static void insert_body(build_ctx *c, int64_t body, int64_t ni, int depth)
+{
+    if (c->err) return;
+    const double bx = c->pos[2 * body], by = c->pos[2 * body + 1], bm = c->mass[body];
+
+    if (c->max_depth > 0 && depth >= c->max_depth) {
+        /* depth-cap aggregation, project.cu:360-382: running mass-weighted mean */
+        bho_node *q = &c->nodes[ni];
+        double m0 = q->mass, x0 = q->comx, y0 = q->comy;
+        q->comx = (m0 * x0 + bm * bx) / (m0 + bm);
+        q->comy = (m0 * y0 + bm * by) / (m0 + bm);
+        q->mass += bm;
+        q->particle = (m0 == 0) ? (double)(-1 * body - 2) : -1.0;
+        return;
+    }
+    if (c->max_depth <= 0 && depth > BHO_UNCAPPED_LIMIT) { c->err = -2; return; }
+
+    bho_node q = c->nodes[ni]; /* working copy, written back where the reference does */
+    int empty_leaf = (q.child[0] == -1 && q.child[1] == -1 && q.child[2] == -1 &&
+                      q.child[3] == -1 && q.mass == 0.0);
+    if (empty_leaf) {
+        q.comx = bx; q.comy = by; q.mass = bm; q.particle = (double)body;
+        c->nodes[ni] = q;
+        return;
+    }
+
+    /* occupied leaf -> split.  project.cu:408 tests `> -1`, ma2.cpp:108 tests `!= -1`. */
+    int occupied = (c->max_depth > 0) ? (q.particle > -1) : (q.particle != -1);
+    if (q.mass > 0.0 && occupied) {
+        if (c->count + 4 > c->cap) { c->err = -1; return; }
+        for (int k = 0; k < 4; ++k) {
+            double mx = (q.xmin + q.xmax) / 2.0;
+            double my = (q.ymin + q.ymax) / 2.0;
+            bho_node *ch = &c->nodes[c->count];
+            if (k == 0)      blank_node(ch, q.xmin, mx, q.ymin, my);
+            else if (k == 1) blank_node(ch, mx, q.xmax, q.ymin, my);
+            else if (k == 2) blank_node(ch, q.xmin, mx, my, q.ymax);
+            else             blank_node(ch, mx, q.xmax, my, q.ymax);
+            q.child[k] = (double)c->count;
+            c->count++;
+        }
+        double ox = q.comx, oy = q.comy;
+        int64_t old_body = (int64_t)q.particle;
+        q.comx = 0.0; q.comy = 0.0; q.mass = 0.0; q.particle = -1;
+        c->nodes[ni] = q;
+        int oc = pick_child(ox, oy, &q);
+        insert_body(c, old_body, (int64_t)q.child[oc], depth + 1);
+    }
+    int nc = pick_child(bx, by, &q);
+    insert_body(c, body, (int64_t)q.child[nc], depth + 1);
+}
+
+/* ---- mass / COM pass: project.cu:473-502 ------------------------------------------- */
+static void mass_pass(bho_node *nodes, int64_t ni, double *m_out, double *x_out, double *y_out)
+{
+    bho_node *q = &nodes[ni];
+    if (q->child[0] == -1) {
+        *m_out = q->mass; *x_out = q->comx; *y_out = q->comy;
+        return;
+    }
+    double tot = 0.0, sx = 0.0, sy = 0.0;
+    for (int k = 0; k < 4; ++k) {
+        if (q->child[k] != -1) {
+            double cm, cx, cy;
+            mass_pass(nodes, (int64_t)q->child[k], &cm, &cx, &cy);
+            tot += cm;
+            sx += cm * cx;
+            sy += cm * cy;
+        }
+    }
+    if (tot > 0.0) { sx /= tot; sy /= tot; }
+    q->mass = tot; q->comx = sx; q->comy = sy;
+    *m_out = tot; *x_out = sx; *y_out = sy;
+}
+
+int64_t bho_build_tree(const double *pos, const double *mass, int64_t n, int max_depth,
+                       bho_node *nodes, int64_t cap)
+{
+    if (cap < 1) return -1;
+    double box[4];
+    bho_root_bounds(pos, n, box);
+    build_ctx c = { nodes, 0, cap, pos, mass, max_depth, 0 };
+    blank_node(&nodes[0], box[0], box[1], box[2], box[3]);
+    c.count = 1;
+    for (int64_t i = 0; i < n; ++i) {
+        insert_body(&c, i, 0, 1); /* root is depth 1, project.cu:587 */
+        if (c.err) return c.err;
+    }
+    double m, x, y;
+    mass_pass(nodes, 0, &m, &x, &y);
+    return c.count;
+}
+
+/* ---- theta walk: project.cu:593-675 / main_approach_2.cpp:261-343 ------------------ */
+void bho_compute_forces_range(const bho_node *nodes, const double *pos, const double *mass,
+                              int64_t lo, int64_t hi, double theta, double G,
+                              int compat_self_skip, double *forces, bho_walk_stats *stats)
+{
+    int64_t scap = 1024, *stack = (int64_t *)malloc(sizeof(int64_t) * scap);
+    uint64_t visits = 0, inter = 0;
+    int32_t deepest = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+        double fx = 0.0, fy = 0.0;
+        const double px = pos[2 * i], py = pos[2 * i + 1];
+        int64_t top = 0;
+        stack[top++] = 0;
+        while (top > 0) {
+            if (top > deepest) deepest = (int32_t)top;
+            const bho_node *q = &nodes[stack[--top]];
+            double qm = q->mass;
+            if (qm <= 1e-15) continue;
+            visits++;
+            int64_t occ = (int64_t)q->particle;
+            int leaf = (q->child[0] == -1 && q->child[1] == -1 && q->child[2] == -1 &&
+                        q->child[3] == -1);
+            double dx = q->comx - px;
+            double dy = q->comy - py;
+            double d2 = dx * dx + dy * dy;
+            double d = sqrt(d2) + 1e-15;
+            double ex = q->xmax - q->xmin, ey = q->ymax - q->ymin;
+            double size = (ex > ey) ? ex : ey;
+            if (leaf || (size / d < theta)) {
+                if (leaf) {
+                    if (occ == i) continue;
+                    if (compat_self_skip && (occ + 2) == -i) continue;
+                }
+                double f = (G * mass[i] * qm) / d2;
+                double ux = dx / d, uy = dy / d;
+                fx += f * ux;
+                fy += f * uy;
+                inter++;
+            } else {
+                if (top + 4 > scap) {
+                    scap *= 2;
+                    stack = (int64_t *)realloc(stack, sizeof(int64_t) * scap);
+                }
+                for (int k = 0; k < 4; ++k) {
+                    int64_t ci = (int64_t)q->child[k];
+                    if (ci != -1) stack[top++] = ci;
+                }
+            }
+        }
+        forces[2 * i] = fx;
+        forces[2 * i + 1] = fy;
+    }
+    free(stack);
+    if (stats) { stats->visits = visits; stats->interactions = inter; stats->max_stack = deepest; }
+}
+
+void bho_compute_forces(const bho_node *nodes, const double *pos, const double *mass,
+                        int64_t n, double theta, double G, int compat_self_skip,
+                        double *forces, bho_walk_stats *stats)
+{
+    bho_compute_forces_range(nodes, pos, mass, 0, n, theta, G, compat_self_skip, forces, stats);
+}
+
+/* ---- direct sum: main_approach_1.cpp:53-75 ----------------------------------------- */
+void bho_direct_forces(const double *pos, const double *mass, int64_t n, double G,
+                       double *forces)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        double sx = 0.0, sy = 0.0;
+        for (int64_t j = 0; j < n; ++j) {
+            if (i == j) continue;
+            double d2 = 0.0;
+            double dx = pos[2 * j] - pos[2 * i];
+            d2 += dx * dx;
+            double dy = pos[2 * j + 1] - pos[2 * i + 1];
+            d2 += dy * dy;
+            double d = sqrt(d2);
+            double k = G * mass[i] * mass[j] / (d2 * d);
+            sx += k * dx;
+            sy += k * dy;
+        }
+        forces[2 * i] = sx;
+        forces[2 * i + 1] = sy;
+    }
+}
+
+/* ---- integrator: project.cu:795-817 ------------------------------------------------ */
+void bho_integrate(const double *forces, const double *mass, int64_t n, double dt,
+                   double *acc, double *vel, double *pos)
+{
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 2; ++k) acc[2 * i + k] = forces[2 * i + k] / mass[i];
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 2; ++k) vel[2 * i + k] += acc[2 * i + k] * dt;
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 2; ++k) pos[2 * i + k] += vel[2 * i + k] * dt;
+}
+
+/* ---- step loop: project.cu:883-910 / main_approach_1.cpp:139-148 ------------------- */
+int bho_run(double *pos, double *vel, const double *mass, int64_t n, int nsteps,
+            int max_depth, double theta, double G, double dt, int use_direct)
+{
+    double *f = (double *)malloc(sizeof(double) * 2 * (size_t)(n > 0 ? n : 1));
+    double *a = (double *)malloc(sizeof(double) * 2 * (size_t)(n > 0 ? n : 1));
+    int64_t cap = 0;
+    bho_node *nodes = NULL;
+    if (!use_direct) {
+        int levels = (max_depth > 0) ? max_depth : BHO_UNCAPPED_LIMIT;
+        cap = 1 + 4 * n * (int64_t)(levels < 64 ? levels : 64);
+        if (max_depth > 0 && max_depth < 15) {
+            int64_t full = 0, w = 1;
+            for (int l = 0; l < max_depth; ++l) { full += w; w *= 4; }
+            if (full < cap) cap = full;
+        }
+        if (cap > 16 * n + 1024) cap = 16 * n + 1024;
+        nodes = (bho_node *)malloc(sizeof(bho_node) * (size_t)cap);
+    }
+    int rc = 0;
+    for (int s = 0; s < nsteps && rc == 0; ++s) {
+        if (use_direct) {
+            bho_direct_forces(pos, mass, n, G, f);
+        } else {
+            int64_t nn = bho_build_tree(pos, mass, n, max_depth, nodes, cap);
+            if (nn < 0) { rc = (int)nn; break; }
+            bho_compute_forces(nodes, pos, mass, n, theta, G, max_depth > 0, f, NULL);
+        }
+        bho_integrate(f, mass, n, dt, a, vel, pos);
+    }
+    free(f); free(a); free(nodes);
+    return rc;
+}
+
+/* ---- DFS pre-order export: traversal order of project.cu:504-534 -------------------- */
+int64_t bho_export_preorder(const bho_node *nodes, int64_t n_nodes, bho_node *out,
+                            int32_t *depth)
+{
+    if (n_nodes < 1) return 0;
+    int64_t *st = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_nodes + 4));
+    int32_t *sd = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_nodes + 4));
+    int64_t top = 0, k = 0;
+    st[top] = 0; sd[top] = 0; top++;
+    while (top > 0) {
+        --top;
+        int64_t ni = st[top];
+        int32_t d = sd[top];
+        out[k] = nodes[ni];
+        if (depth) depth[k] = d;
+        k++;
+        for (int c = 3; c >= 0; --c) { /* push reversed so child 0 is visited first */
+            int64_t ci = (int64_t)nodes[ni].child[c];
+            if (ci != -1) { st[top] = ci; sd[top] = d + 1; top++; }
+        }
+    }
+    free(st); free(sd);
+    return k;
+}
+
+/* ---- text dump: project.cu:504-534 -------------------------------------------------- */
+int64_t bho_write_tree_text(const bho_node *nodes, int64_t n_nodes, const double *pos,
+                            const char *path)
+{
+    FILE *fp = fopen(path, "w");
+    if (!fp) return -1;
+    bho_node *ord = (bho_node *)malloc(sizeof(bho_node) * (size_t)n_nodes);
+    int32_t *dep = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_nodes);
+    int64_t k = bho_export_preorder(nodes, n_nodes, ord, dep);
+    for (int64_t i = 0; i < k; ++i) {
+        const bho_node *q = &ord[i];
+        fprintf(fp, "%d %g %g %g %g %g", dep[i], q->xmin, q->xmax, q->ymin, q->ymax, q->mass);
+        int64_t occ = (int64_t)q->particle;
+        if (occ != -1) {
+            /* the reference indexes positions[occ] even for occ <= -2 (out of bounds);
+             * the body meant is -(occ+2), whose true position is printed here */
+            int64_t b = (occ >= 0) ? occ : -(occ + 2);
+            fprintf(fp, " occupantIndex=%lld occupantPos=(%g,%g)", (long long)occ,
+                    pos[2 * b], pos[2 * b + 1]);
+        } else if (q->mass > 0) {
+            fprintf(fp, " occupantIndex=%lld occupantPos=(%g,%g)", (long long)occ, q->comx,
+                    q->comy);
+        }
+        fputc('\n', fp);
+    }
+    fclose(fp);
+    free(ord); free(dep);
+    return k;
+}
+
+/* ---- work-sharing calibration ---------------------------------------- */
+uint64_t bho_group_union_visits(const bho_node *nodes, int64_t n_nodes, const double *pos,
+                                const int64_t *order, int64_t n, int group, double theta)
+{
+    int64_t *mark = (int64_t *)malloc(sizeof(int64_t) * (size_t)n_nodes);
+    for (int64_t i = 0; i < n_nodes; ++i) mark[i] = -1;
+    int64_t scap = 1024, *stack = (int64_t *)malloc(sizeof(int64_t) * scap);
+    uint64_t total = 0;
+    for (int64_t g0 = 0; g0 < n; g0 += group) {
+        int64_t g1 = g0 + group < n ? g0 + group : n;
+        for (int64_t s = g0; s < g1; ++s) {
+            int64_t i = order[s];
+            const double px = pos[2 * i], py = pos[2 * i + 1];
+            int64_t top = 0;
+            stack[top++] = 0;
+            while (top > 0) {
+                int64_t ni = stack[--top];
+                const bho_node *q = &nodes[ni];
+                if (q->mass <= 1e-15) continue;
+                if (mark[ni] != g0) { mark[ni] = g0; total++; }
+                int leaf = (q->child[0] == -1);
+                double dx = q->comx - px, dy = q->comy - py;
+                double d = sqrt(dx * dx + dy * dy) + 1e-15;
+                double ex = q->xmax - q->xmin, ey = q->ymax - q->ymin;
+                double size = (ex > ey) ? ex : ey;
+                if (leaf || (size / d < theta)) continue;
+                if (top + 4 > scap) {
+                    scap *= 2;
+                    stack = (int64_t *)realloc(stack, sizeof(int64_t) * scap);
+                }
+                for (int k = 0; k < 4; ++k) {
+                    int64_t ci = (int64_t)q->child[k];
+                    if (ci != -1) stack[top++] = ci;
+                }
+            }
+        }
+    }
+    free(mark); free(stack);
+    return total;
+}

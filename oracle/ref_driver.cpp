@@ -1,0 +1,135 @@
+// ref_driver.cpp -- links against the REFERENCE's own compiled functions and dumps their
+// results at full fp64 precision.  TEST INFRASTRUCTURE ONLY (development container only:
+// the reference sources never leave /root/reference; see oracle/Makefile target `ref`).
+//
+// Nothing here re-implements the reference: the functions called below are the ones
+// defined in /root/reference/implementation/{project.cu, main_approach_1.cpp,
+// main_approach_2.cpp}, compiled from where they lie with `main` renamed by -Dmain=...
+// so that this file can supply the entry point.  Which of the three it links against is
+// selected with -DREF_KIND=1 (project.cu CPU path), 2 (main_approach_2.cpp) or
+// 3 (main_approach_1.cpp).
+//
+// usage: ref_driver <init_dir> <n_steps> <out_dir> <dump_step>[,<dump_step>...]
+//   reads   <init_dir>/{masses,positions,velocities}_init.txt   (first N_BODIES lines)
+//   writes  <out_dir>/tree_<s>.bin   (n_nodes x 12 fp64, tree built at the START of step s)
+//           <out_dir>/forces_<s>.bin (N x 2 fp64, forces of step s)
+//           <out_dir>/pos_<s>.bin, vel_<s>.bin (state AFTER step s)
+//           <out_dir>/quadtree_<s>.txt (the reference's own text dump, REF_KIND 1/2)
+#include <array>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#ifndef REF_KIND
+#error "define REF_KIND"
+#endif
+
+#if REF_KIND == 1
+#ifndef N_BODIES
+#error "REF_KIND 1 needs -DN_BODIES=<n>, the same value the reference object was built with"
+#endif
+constexpr int kN = N_BODIES;
+#elif REF_KIND == 2
+constexpr int kN = 1000;   // main_approach_2.cpp:14
+#else
+#ifndef REF_MA1_N
+#error "REF_KIND 3 needs -DREF_MA1_N=<n>, the value main_approach_1.cpp:12 was set to"
+#endif
+constexpr int kN = REF_MA1_N;
+#endif
+
+using Vector = std::array<double, 2>;
+using Positions = std::array<Vector, kN>;
+using Velocities = std::array<Vector, kN>;
+using Forces = std::array<Vector, kN>;
+using Masses = std::array<double, kN>;
+using Quadrant = std::array<double, 12>;
+
+// ---- the reference's functions (declarations only; definitions are the reference's) ----
+void computeForces(const Positions&, const Masses&, Forces&);
+void updateAccelerations(const Forces&, const Masses&, Positions&);
+void updateVelocities(Velocities&, const Positions&, double);
+void updatePositions(Positions&, const Velocities&, double);
+#if REF_KIND != 3
+extern std::vector<Quadrant> quadtree;
+std::vector<Quadrant> buildTree(const Positions&, const Masses&);
+void TraverseTreeToFile(int, std::ofstream&, const Positions&, int);
+#endif
+#if REF_KIND == 1
+void loadSimulationDataFromText(const std::string&, const std::string&, const std::string&,
+                                size_t, Masses&, Positions&, Velocities&);
+#endif
+
+static void dump(const std::string& path, const void* p, size_t bytes) {
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) { std::perror(path.c_str()); std::exit(2); }
+    std::fwrite(p, 1, bytes, f);
+    std::fclose(f);
+}
+
+#if REF_KIND != 1
+// main_approach_1/2 have no file loader; the same three text files are read here with
+// the same stream extraction the reference's loader uses.
+static void load_plain(const std::string& dir, Masses& m, Positions& p, Velocities& v) {
+    std::ifstream fm(dir + "/masses_init.txt"), fp(dir + "/positions_init.txt"),
+        fv(dir + "/velocities_init.txt");
+    if (!fm || !fp || !fv) { std::cerr << "missing init files in " << dir << "\n"; std::exit(2); }
+    for (int i = 0; i < kN; ++i) {
+        if (!(fm >> m[i]) || !(fp >> p[i][0] >> p[i][1]) || !(fv >> v[i][0] >> v[i][1])) {
+            std::cerr << "short init file\n"; std::exit(2);
+        }
+    }
+}
+#endif
+
+int main(int argc, char** argv) {
+    if (argc < 5) { std::cerr << "usage: ref_driver init_dir n_steps out_dir s0,s1,...\n"; return 2; }
+    const std::string dir = argv[1], out = argv[3];
+    const int n_steps = std::atoi(argv[2]);
+    std::set<int> dumps;
+    { std::stringstream ss(argv[4]); std::string tok; while (std::getline(ss, tok, ',')) dumps.insert(std::atoi(tok.c_str())); }
+
+    auto masses = std::make_unique<Masses>();
+    auto pos = std::make_unique<Positions>();
+    auto vel = std::make_unique<Velocities>();
+    auto acc = std::make_unique<Positions>();
+    auto frc = std::make_unique<Forces>();
+    acc->fill({0, 0}); frc->fill({0, 0});
+
+#if REF_KIND == 1
+    loadSimulationDataFromText(dir + "/masses_init.txt", dir + "/positions_init.txt",
+                               dir + "/velocities_init.txt", kN, *masses, *pos, *vel);
+#else
+    load_plain(dir, *masses, *pos, *vel);
+#endif
+
+    const double dt = 1.0;   // DELTA_T / delta_t of all three programs
+    for (int s = 0; s < n_steps; ++s) {
+        const bool d = dumps.count(s) != 0;
+        const std::string tag = std::to_string(s);
+#if REF_KIND != 3
+        quadtree = buildTree(*pos, *masses);
+        if (d) {
+            dump(out + "/tree_" + tag + ".bin", quadtree.data(), quadtree.size() * sizeof(Quadrant));
+            std::ofstream tf(out + "/quadtree_" + tag + ".txt");
+            TraverseTreeToFile(0, tf, *pos, 0);
+        }
+#endif
+        computeForces(*pos, *masses, *frc);
+        if (d) dump(out + "/forces_" + tag + ".bin", frc->data(), sizeof(Forces));
+        updateAccelerations(*frc, *masses, *acc);
+        updateVelocities(*vel, *acc, dt);
+        updatePositions(*pos, *vel, dt);
+        if (d) {
+            dump(out + "/pos_" + tag + ".bin", pos->data(), sizeof(Positions));
+            dump(out + "/vel_" + tag + ".bin", vel->data(), sizeof(Velocities));
+        }
+    }
+    return 0;
+}
