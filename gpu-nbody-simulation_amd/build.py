@@ -1,0 +1,66 @@
+"""Builds libbhgpu.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+    python -m gpu_nbody_simulation_amd.build
+
+hipcc cross-compiles without a GPU.  Two translation units: bh_engine.hip (tree build, exact
+walk, C-ABI) with -ffp-contract=off so fp64 results stay bit-identical to the reference, and
+bh_walk_fast.hip (fp32 walk) with the default contraction.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libbhgpu.so")
+ARCH = "gfx950"
+
+UNITS = [
+    ("bh_engine.hip", ["-ffp-contract=off"]),
+    ("bh_walk_fast.hip", []),
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm; this library has no non-HIP build)")
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
+        os.path.join(HERE, "..", "include", "bhgpu.h")]
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = _hipcc()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    for src, extra in UNITS:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall",
+               "-Wno-unused-function", *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+        objs.append(obj)
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

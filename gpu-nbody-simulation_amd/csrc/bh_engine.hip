@@ -1,0 +1,730 @@
+// bh_engine.hip -- libbhgpu.so: context, per-step pipeline and the C-ABI of include/bhgpu.h.
+// Compiled with -ffp-contract=off (tree build + exact walk must not fuse multiply-adds; the fp32
+// walk lives in bh_walk_fast.hip, compiled separately).  gfx950 only, no CPU fallback.
+#include "../../include/bhgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bh_tree.hpp"
+#include "bh_walk_exact.hpp"
+#include "bh_walk_fast.h"
+
+using namespace bh;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct bh_ctx {
+    bh_config cfg{};
+    int Dm = 0;
+    bool exact = true, compat = true;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t n = 0;
+    bool uploaded = false, tree_valid = false;
+    int64_t internal_cap = 0, node_cap = 0;
+    int sort_passes = 0;
+
+    // caller-order state (double2/double or float2/float)
+    void *pos = nullptr, *vel = nullptr, *mass = nullptr, *force = nullptr;
+    // sorted-order copies (fp32 mode)
+    float2 *spos = nullptr, *spos_out = nullptr, *svel = nullptr;
+    float *smass = nullptr;
+    // sort
+    uint64_t *keys[2] = {nullptr, nullptr};
+    uint32_t *vals[2] = {nullptr, nullptr};
+    uint64_t *keys_sorted = nullptr;
+    uint32_t *perm = nullptr;
+    uint32_t *radix_counts = nullptr, *bsum_u32 = nullptr, *cnt = nullptr;
+    d3 *terms = nullptr, *bsum_d3 = nullptr;
+    double *partial = nullptr, *box = nullptr;
+    // tree
+    NodeD *gd = nullptr;
+    LinkD *ld = nullptr;
+    NodeF *nf = nullptr;
+    int32_t *self_node = nullptr, *cell_depth = nullptr;
+    TreeCounters *ctr = nullptr;
+
+    // ownership (multi-GPU): sorted range [lo, hi) = rank's share
+    int rank = 0, world = 1;
+
+    // measurement
+    std::vector<hipEvent_t> ev;        // pairs around the walk kernel, one pair per step
+    hipEvent_t ev_step[2] = {nullptr, nullptr}, ev_build[2] = {nullptr, nullptr};
+    int64_t steps_done = 0;
+    int32_t last_nsteps = 0;
+    int timed_pairs = 0;
+    bool step_timed = false;
+
+    std::vector<void *> allocs;
+    uint64_t device_bytes = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(bh_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define BH_HIP(c, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail((c), BH_ERR_DEVICE,                                                     \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                     \
+    } while (0)
+
+template <typename T>
+int dev_alloc(bh_ctx *c, T **out, size_t count)
+{
+    void *p = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess)
+        return fail(c, BH_ERR_DEVICE, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    c->allocs.push_back(p);
+    c->device_bytes += bytes;
+    *out = static_cast<T *>(p);
+    return BH_OK;
+}
+
+inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+void owned_range(const bh_ctx *c, int64_t *lo, int64_t *hi)
+{
+    *lo = c->n * c->rank / c->world;
+    *hi = c->n * (c->rank + 1) / c->world;
+}
+
+// exclusive scan of `len` uint32 in place; total (if non-null) receives the sum
+int enqueue_scan_u32(bh_ctx *c, uint32_t *data, int64_t len, uint32_t *total)
+{
+    if (len <= 0) return BH_OK;
+    const unsigned nb = blocks_for(len, kTile);
+    hipLaunchKernelGGL((scan_tile_sums<uint32_t>), dim3(nb), dim3(kBlock), 0, c->stream, data, c->bsum_u32, len);
+    hipLaunchKernelGGL((scan_top<uint32_t>), dim3(1), dim3(kBlock), 0, c->stream, c->bsum_u32, (int)nb, total);
+    hipLaunchKernelGGL((scan_apply<uint32_t>), dim3(nb), dim3(kBlock), 0, c->stream, data, data, c->bsum_u32, len);
+    BH_HIP(c, hipGetLastError());
+    return BH_OK;
+}
+
+int enqueue_scan_d3(bh_ctx *c, d3 *data, int64_t len)
+{
+    if (len <= 0) return BH_OK;
+    const unsigned nb = blocks_for(len, kTile);
+    hipLaunchKernelGGL((scan_tile_sums<d3>), dim3(nb), dim3(kBlock), 0, c->stream, data, c->bsum_d3, len);
+    hipLaunchKernelGGL((scan_top<d3>), dim3(1), dim3(kBlock), 0, c->stream, c->bsum_d3, (int)nb, (d3 *)nullptr);
+    hipLaunchKernelGGL((scan_apply<d3>), dim3(nb), dim3(kBlock), 0, c->stream, data, data, c->bsum_d3, len);
+    BH_HIP(c, hipGetLastError());
+    return BH_OK;
+}
+
+template <bool EXACT>
+int enqueue_build_t(bh_ctx *c)
+{
+    using Real2 = typename std::conditional<EXACT, double2, float2>::type;
+    using Real = typename std::conditional<EXACT, double, float>::type;
+    const int64_t n = c->n;
+    const int Dm = c->Dm;
+    hipStream_t st = c->stream;
+    const Real2 *pos = static_cast<const Real2 *>(c->pos);
+    const Real *mass = static_cast<const Real *>(c->mass);
+
+    // 1. root box (ComputeRootBounds, project.cu:536-573)
+    const unsigned nbb = std::max(1u, std::min(1024u, blocks_for(n, kBlock)));
+    hipLaunchKernelGGL((bounds_partial<Real2>), dim3(nbb), dim3(kBlock), 0, st, pos, n, c->partial);
+    hipLaunchKernelGGL(bounds_final, dim3(1), dim3(kBlock), 0, st, c->partial, (int)nbb, c->box);
+    BH_HIP(c, hipMemsetAsync(c->ctr, 0, sizeof(TreeCounters), st));
+
+    if (n > 0) {
+        // 2. keys by fp64 bisection, 3. stable radix sort
+        hipLaunchKernelGGL((keys_kernel<Real2>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
+                           c->box, c->keys[0], c->vals[0], n, Dm);
+        const unsigned nbl = blocks_for(n, kTile);
+        int cur = 0;
+        for (int p = 0; p < c->sort_passes; ++p) {
+            const int shift = p * kRadixBits;
+            hipLaunchKernelGGL((radix_hist<uint64_t>), dim3(nbl), dim3(kBlock), 0, st, c->keys[cur],
+                               c->radix_counts, n, shift, (int)nbl);
+            int rc = enqueue_scan_u32(c, c->radix_counts, (int64_t)kRadix * nbl, nullptr);
+            if (rc) return rc;
+            hipLaunchKernelGGL((radix_scatter<uint64_t>), dim3(nbl), dim3(kBlock), 0, st, c->keys[cur],
+                               c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1], c->radix_counts, n,
+                               shift, (int)nbl);
+            cur ^= 1;
+        }
+        c->keys_sorted = c->keys[cur];
+        c->perm = c->vals[cur];
+
+        // 4. cells owned by each sorted neighbour pair, 5. their ranks
+        hipLaunchKernelGGL(pairs_kernel, dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, c->keys_sorted,
+                           c->cnt, n, Dm);
+        int rc = enqueue_scan_u32(c, c->cnt, n, &c->ctr->n_internal);
+        if (rc) return rc;
+
+        if (!EXACT) {
+            hipLaunchKernelGGL((gather_sorted_kernel<Real2, Real>), dim3(blocks_for(n + 1, kBlock)),
+                               dim3(kBlock), 0, st, c->perm, pos, mass, (Real2 *)c->spos, (Real *)c->smass,
+                               c->terms, n);
+            rc = enqueue_scan_d3(c, c->terms, n + 1);
+            if (rc) return rc;
+        }
+    } else {
+        c->keys_sorted = c->keys[0];
+        c->perm = c->vals[0];
+    }
+
+    // 6. nodes
+    hipLaunchKernelGGL((root_only_kernel<EXACT, Real2, Real>), dim3(1), dim3(64), 0, st, pos, mass, c->perm,
+                       c->box, n, Dm, c->cfg.theta, c->gd, c->ld, c->nf, c->ctr);
+    if (n > 1) {
+        hipLaunchKernelGGL((nodes_kernel<EXACT, Real2, Real>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st,
+                           c->keys_sorted, c->perm, c->cnt, pos, mass, c->box, c->terms, n, Dm, c->cfg.theta,
+                           c->internal_cap, c->gd, c->ld, c->nf, c->self_node, c->cell_depth, c->ctr);
+        // 7. exact bottom-up mass pass (ComputeMass, project.cu:473-502)
+        if (EXACT) {
+            const int64_t span = std::min<int64_t>(c->internal_cap, std::max<int64_t>(1, (n - 1) * (int64_t)std::max(1, Dm)));
+            for (int d = Dm - 1; d >= 0; --d)
+                hipLaunchKernelGGL(com_level_kernel, dim3(blocks_for(span, kBlock)), dim3(kBlock), 0, st, c->gd,
+                                   c->ld, c->self_node, c->cell_depth, c->ctr, c->internal_cap, d);
+        }
+    }
+    BH_HIP(c, hipGetLastError());
+    c->tree_valid = true;
+    return BH_OK;
+}
+
+int enqueue_build(bh_ctx *c) { return c->exact ? enqueue_build_t<true>(c) : enqueue_build_t<false>(c); }
+
+int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted)
+{
+    int64_t lo, hi;
+    owned_range(c, &lo, &hi);
+    if (hi <= lo) return BH_OK;
+    const bool stats = (c->cfg.flags & BH_FLAG_WALK_STATS) != 0;
+    if (c->exact) {
+        const unsigned grid = blocks_for(hi - lo, kBlock);
+        auto args = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, c->stream, c->gd, c->ld, c->perm,
+                               (double2 *)c->pos, (double2 *)c->vel, (const double *)c->mass,
+                               (double2 *)c->force, lo, hi, c->cfg.theta, c->cfg.G, c->cfg.dt,
+                               integrate ? 1 : 0, c->ctr);
+        };
+        if (c->compat) { if (stats) args(walk_exact_kernel<true, true>); else args(walk_exact_kernel<true, false>); }
+        else           { if (stats) args(walk_exact_kernel<false, true>); else args(walk_exact_kernel<false, false>); }
+        BH_HIP(c, hipGetLastError());
+    } else {
+        WalkFastArgs a{};
+        a.nodes = c->nf; a.spos = c->spos; a.smass = c->smass; a.perm = c->perm;
+        a.pos = (float2 *)c->pos; a.vel = (float2 *)c->vel;
+        a.spos_out = c->spos_out; a.svel = c->svel;
+        a.acc_out = (float2 *)c->force; a.ctr = c->ctr;
+        a.lo = lo; a.hi = hi; a.G = (float)c->cfg.G; a.dt = (float)c->cfg.dt;
+        a.integrate = integrate ? 1 : 0; a.to_sorted = to_sorted ? 1 : 0;
+        const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0 || (3 * c->Dm + 4 > kWave);
+        BH_HIP(c, launch_walk_fast(a, lds, stats, !c->compat, c->stream));
+    }
+    return BH_OK;
+}
+
+int check_overflow(bh_ctx *c)
+{
+    TreeCounters h{};
+    BH_HIP(c, hipMemcpyAsync(&h, c->ctr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+    if (h.overflow || (int64_t)h.n_internal > c->internal_cap)
+        return fail(c, BH_ERR_CAPACITY, "tree needs " + std::to_string(1 + 4 * (int64_t)h.n_internal) +
+                                        " nodes, node_capacity is " + std::to_string(c->node_cap));
+    return BH_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int bh_abi_version(void) { return BHGPU_ABI_VERSION; }
+
+const char *bh_last_error(const bh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int bh_create(const bh_config *cfg, bh_ctx **out)
+{
+    if (!cfg || !out) return fail(nullptr, BH_ERR_ARG, "bh_create: null argument");
+    *out = nullptr;
+    if (cfg->capacity < 0 || cfg->capacity > 0x7fffffffLL - 8)
+        return fail(nullptr, BH_ERR_ARG, "bh_create: capacity out of range");
+    if (cfg->max_depth < 1 || cfg->max_depth > 32)
+        return fail(nullptr, BH_ERR_ARG, "bh_create: max_depth must be 1..32");
+    if (!(cfg->theta > 0.0)) return fail(nullptr, BH_ERR_ARG, "bh_create: theta must be > 0");
+    if (cfg->precision != BH_PRECISION_F64_EXACT && cfg->precision != BH_PRECISION_F32)
+        return fail(nullptr, BH_ERR_ARG, "bh_create: unknown precision");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, BH_ERR_NO_DEVICE, "bh_create: no HIP device (libbhgpu has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, BH_ERR_ARG, "bh_create: device ordinal out of range");
+
+    bh_ctx *c = new bh_ctx();
+    c->cfg = *cfg;
+    c->Dm = cfg->max_depth - 1;
+    c->exact = cfg->precision == BH_PRECISION_F64_EXACT;
+    c->compat = cfg->reference_compat != 0;
+    c->device = cfg->device;
+    c->sort_passes = (2 * c->Dm + kRadixBits - 1) / kRadixBits;
+    auto bail = [&](int rc) { g_create_error = c->err; bh_destroy(c); return rc; };
+
+    if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(BH_ERR_DEVICE); }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        c->err = "hipStreamCreate failed"; return bail(BH_ERR_DEVICE);
+    }
+    c->own_stream = true;
+
+    const int64_t cap = std::max<int64_t>(cfg->capacity, 1);
+    c->node_cap = cfg->node_capacity > 0 ? cfg->node_capacity : 8 * cap + 1024;
+    // a depth-capped tree can never exceed the full tree (QUADTREE_MAX_SIZE, project.cu:62)
+    if (c->Dm < 15) {
+        int64_t full = 0, wdt = 1;
+        for (int l = 0; l <= c->Dm; ++l) { full += wdt; wdt *= 4; }
+        c->node_cap = std::min(c->node_cap, std::max<int64_t>(full, 1));
+    }
+    c->internal_cap = (c->node_cap - 1) / 4;
+
+    const size_t rs = c->exact ? sizeof(double) : sizeof(float);
+    int rc = 0;
+    auto A = [&](auto **pp, size_t count) { if (!rc) rc = dev_alloc(c, pp, count); };
+    { char *t; A(&t, cap * 2 * rs); c->pos = t; }
+    { char *t; A(&t, cap * 2 * rs); c->vel = t; }
+    { char *t; A(&t, cap * rs); c->mass = t; }
+    { char *t; A(&t, cap * 2 * rs); c->force = t; }
+    A(&c->keys[0], cap); A(&c->keys[1], cap); A(&c->vals[0], cap); A(&c->vals[1], cap);
+    A(&c->cnt, cap + 1);
+    const size_t nbl = blocks_for(cap, kTile);
+    A(&c->radix_counts, (size_t)kRadix * nbl);
+    A(&c->bsum_u32, std::max<size_t>(blocks_for((int64_t)kRadix * nbl, kTile), nbl) + 8);
+    A(&c->partial, 4 * 1024); A(&c->box, 4);
+    A(&c->ctr, 1);
+    if (c->exact) {
+        A(&c->gd, c->node_cap); A(&c->ld, c->node_cap);
+        A(&c->self_node, c->internal_cap + 1); A(&c->cell_depth, c->internal_cap + 1);
+    } else {
+        A(&c->nf, c->node_cap);
+        A(&c->spos, cap); A(&c->spos_out, cap); A(&c->svel, cap); A(&c->smass, cap);
+        A(&c->terms, cap + 1); A(&c->bsum_d3, blocks_for(cap + 1, kTile) + 8);
+    }
+    if (rc) return bail(rc);
+    for (auto &e : c->ev_step) if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(BH_ERR_DEVICE); }
+    for (auto &e : c->ev_build) if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(BH_ERR_DEVICE); }
+    *out = c;
+    return BH_OK;
+}
+
+void bh_destroy(bh_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void *p : c->allocs) (void)hipFree(p);
+    for (auto e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto e : c->ev_step) if (e) (void)hipEventDestroy(e);
+    for (auto e : c->ev_build) if (e) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bh_set_stream(bh_ctx *c, void *hip_stream)
+{
+    if (!c) return BH_ERR_ARG;
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    c->own_stream = false;
+    return BH_OK;
+}
+
+int bh_upload(bh_ctx *c, const double *pos, const double *vel, const double *mass, int64_t n)
+{
+    if (!c) return BH_ERR_ARG;
+    if (n < 0 || (n > 0 && (!pos || !vel || !mass))) return fail(c, BH_ERR_ARG, "bh_upload: null array");
+    if (n > c->cfg.capacity)
+        return fail(c, BH_ERR_ARG, "Requested number of bodies exceeds N_BODIES.");   // project.cu:110-112
+    BH_HIP(c, hipSetDevice(c->device));
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->exact) {
+        BH_HIP(c, hipMemcpy(c->pos, pos, n * 2 * sizeof(double), hipMemcpyHostToDevice));
+        BH_HIP(c, hipMemcpy(c->vel, vel, n * 2 * sizeof(double), hipMemcpyHostToDevice));
+        BH_HIP(c, hipMemcpy(c->mass, mass, n * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> t(std::max<int64_t>(2 * n, 1));
+        for (int64_t i = 0; i < 2 * n; ++i) t[i] = (float)pos[i];
+        BH_HIP(c, hipMemcpy(c->pos, t.data(), n * 2 * sizeof(float), hipMemcpyHostToDevice));
+        for (int64_t i = 0; i < 2 * n; ++i) t[i] = (float)vel[i];
+        BH_HIP(c, hipMemcpy(c->vel, t.data(), n * 2 * sizeof(float), hipMemcpyHostToDevice));
+        for (int64_t i = 0; i < n; ++i) t[i] = (float)mass[i];
+        BH_HIP(c, hipMemcpy(c->mass, t.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    BH_HIP(c, hipMemset(c->force, 0, std::max<int64_t>(n, 1) * 2 * (c->exact ? sizeof(double) : sizeof(float))));
+    c->n = n;
+    c->uploaded = true;
+    c->tree_valid = false;
+    c->steps_done = 0;
+    return BH_OK;
+}
+
+static int download_pairs(bh_ctx *c, const void *dev, double *host, int64_t count)
+{
+    if (c->exact) {
+        BH_HIP(c, hipMemcpy(host, dev, count * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+        std::vector<float> t(std::max<int64_t>(count, 1));
+        BH_HIP(c, hipMemcpy(t.data(), dev, count * sizeof(float), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < count; ++i) host[i] = (double)t[i];
+    }
+    return BH_OK;
+}
+
+int bh_sync(bh_ctx *c)
+{
+    if (!c) return BH_ERR_ARG;
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+    return BH_OK;
+}
+
+int bh_download(bh_ctx *c, double *pos, double *vel)
+{
+    if (!c || !pos) return fail(c, BH_ERR_ARG, "bh_download: null array");
+    if (!c->uploaded) return fail(c, BH_ERR_STATE, "bh_download before bh_upload");
+    BH_HIP(c, hipSetDevice(c->device));
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = download_pairs(c, c->pos, pos, 2 * c->n);
+    if (rc) return rc;
+    if (vel) rc = download_pairs(c, c->vel, vel, 2 * c->n);
+    return rc;
+}
+
+int bh_build_tree(bh_ctx *c)
+{
+    if (!c) return BH_ERR_ARG;
+    if (!c->uploaded) return fail(c, BH_ERR_STATE, "bh_build_tree before bh_upload");
+    BH_HIP(c, hipSetDevice(c->device));
+    int rc = enqueue_build(c);
+    if (rc) return rc;
+    return check_overflow(c);
+}
+
+int bh_compute_forces(bh_ctx *c)
+{
+    if (!c) return BH_ERR_ARG;
+    if (!c->uploaded) return fail(c, BH_ERR_STATE, "bh_compute_forces before bh_upload");
+    BH_HIP(c, hipSetDevice(c->device));
+    int rc = enqueue_build(c);
+    if (rc) return rc;
+    rc = enqueue_walk(c, false, false);
+    if (rc) return rc;
+    return check_overflow(c);
+}
+
+int bh_step(bh_ctx *c, int32_t nsteps)
+{
+    if (!c || nsteps < 0) return BH_ERR_ARG;
+    if (!c->uploaded) return fail(c, BH_ERR_STATE, "bh_step before bh_upload");
+    BH_HIP(c, hipSetDevice(c->device));
+    // one event pair per step around the walk kernel (bounded pool)
+    const int want = std::min<int>(nsteps, 4096);
+    while ((int)c->ev.size() < 2 * want) {
+        hipEvent_t e;
+        BH_HIP(c, hipEventCreate(&e));
+        c->ev.push_back(e);
+    }
+    BH_HIP(c, hipEventRecord(c->ev_step[0], c->stream));
+    for (int s = 0; s < nsteps; ++s) {
+        if (s == nsteps - 1) BH_HIP(c, hipEventRecord(c->ev_build[0], c->stream));
+        int rc = enqueue_build(c);
+        if (rc) return rc;
+        if (s == nsteps - 1) BH_HIP(c, hipEventRecord(c->ev_build[1], c->stream));
+        if (s < want) BH_HIP(c, hipEventRecord(c->ev[2 * s], c->stream));
+        rc = enqueue_walk(c, true, false);
+        if (rc) return rc;
+        if (s < want) BH_HIP(c, hipEventRecord(c->ev[2 * s + 1], c->stream));
+    }
+    BH_HIP(c, hipEventRecord(c->ev_step[1], c->stream));
+    c->steps_done += nsteps;
+    c->last_nsteps = nsteps;
+    c->timed_pairs = want;
+    c->step_timed = nsteps > 0;
+    return BH_OK;
+}
+
+int bh_get_forces(bh_ctx *c, double *out)
+{
+    if (!c || !out) return fail(c, BH_ERR_ARG, "bh_get_forces: null array");
+    BH_HIP(c, hipSetDevice(c->device));
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = download_pairs(c, c->force, out, 2 * c->n);
+    if (rc) return rc;
+    if (!c->exact) {   // fp32 mode stores accelerations; force = a * m_i
+        std::vector<float> m(std::max<int64_t>(c->n, 1));
+        BH_HIP(c, hipMemcpy(m.data(), c->mass, c->n * sizeof(float), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < c->n; ++i) { out[2 * i] *= (double)m[i]; out[2 * i + 1] *= (double)m[i]; }
+    }
+    return BH_OK;
+}
+
+int bh_get_accel(bh_ctx *c, double *out)
+{
+    if (!c || !out) return fail(c, BH_ERR_ARG, "bh_get_accel: null array");
+    BH_HIP(c, hipSetDevice(c->device));
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = download_pairs(c, c->force, out, 2 * c->n);
+    if (rc) return rc;
+    if (c->exact) {    // exact mode stores forces; a = F / m_i (updateAccelerations, project.cu:795-801)
+        std::vector<double> m(std::max<int64_t>(c->n, 1));
+        BH_HIP(c, hipMemcpy(m.data(), c->mass, c->n * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < c->n; ++i) { out[2 * i] /= m[i]; out[2 * i + 1] /= m[i]; }
+    }
+    return BH_OK;
+}
+
+// ---- tree export: DFS pre-order, children in index order (TraverseTreeToFile, project.cu:504-534)
+static int export_tree_host(bh_ctx *c, std::vector<bh_tree_node> &out, std::vector<int32_t> &depth)
+{
+    if (!c->tree_valid) return fail(c, BH_ERR_STATE, "no tree built yet");
+    BH_HIP(c, hipSetDevice(c->device));
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+    TreeCounters h{};
+    BH_HIP(c, hipMemcpy(&h, c->ctr, sizeof(h), hipMemcpyDeviceToHost));
+    if (h.overflow || (int64_t)h.n_internal > c->internal_cap) return fail(c, BH_ERR_CAPACITY, "tree overflowed node_capacity");
+    const int64_t nn = 1 + 4 * (int64_t)h.n_internal;
+    double box[4];
+    BH_HIP(c, hipMemcpy(box, c->box, sizeof(box), hipMemcpyDeviceToHost));
+    std::vector<NodeD> gd;
+    std::vector<LinkD> ld;
+    std::vector<NodeF> nf;
+    std::vector<uint32_t> perm(std::max<int64_t>(c->n, 1));
+    if (c->n > 0) BH_HIP(c, hipMemcpy(perm.data(), c->perm, c->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (c->exact) {
+        gd.resize(nn); ld.resize(nn);
+        BH_HIP(c, hipMemcpy(gd.data(), c->gd, nn * sizeof(NodeD), hipMemcpyDeviceToHost));
+        BH_HIP(c, hipMemcpy(ld.data(), c->ld, nn * sizeof(LinkD), hipMemcpyDeviceToHost));
+    } else {
+        nf.resize(nn);
+        BH_HIP(c, hipMemcpy(nf.data(), c->nf, nn * sizeof(NodeF), hipMemcpyDeviceToHost));
+    }
+    struct Item { int32_t node; int32_t depth; int64_t parent_out; int slot; double x0, x1, y0, y1; };
+    std::vector<Item> stack;
+    stack.push_back({0, 0, -1, 0, box[0], box[1], box[2], box[3]});
+    out.clear(); depth.clear();
+    out.reserve(nn); depth.reserve(nn);
+    while (!stack.empty()) {
+        const Item it = stack.back();
+        stack.pop_back();
+        if (it.node < 0 || it.node >= nn) return fail(c, BH_ERR_DEVICE, "corrupt child link in device tree");
+        bh_tree_node q{};
+        int32_t child;
+        if (c->exact) {
+            q.comx = gd[it.node].cx; q.comy = gd[it.node].cy; q.mass = gd[it.node].m;
+            q.particle = (double)ld[it.node].occ;
+            child = ld[it.node].child;
+        } else {
+            const NodeF &f = nf[it.node];
+            q.comx = f.cx; q.comy = f.cy; q.mass = f.m;
+            child = f.child;
+            if (f.occ >= 0) {
+                const int64_t body = perm[f.occ];
+                q.particle = (it.depth == c->Dm) ? (double)(-body - 2) : (double)body;
+            } else q.particle = -1.0;
+        }
+        q.xmin = it.x0; q.xmax = it.x1; q.ymin = it.y0; q.ymax = it.y1;
+        for (int k = 0; k < 4; ++k) q.child[k] = -1.0;
+        const int64_t me = (int64_t)out.size();
+        if (it.parent_out >= 0) out[it.parent_out].child[it.slot] = (double)me;
+        out.push_back(q);
+        depth.push_back(it.depth);
+        if (child >= 0) {
+            const double mx = (it.x0 + it.x1) / 2.0, my = (it.y0 + it.y1) / 2.0;
+            for (int k = 3; k >= 0; --k) {          // push reversed: child 0 is visited first
+                Item ch{child + k, it.depth + 1, me, k,
+                        (k & 1) ? mx : it.x0, (k & 1) ? it.x1 : mx,
+                        (k & 2) ? my : it.y0, (k & 2) ? it.y1 : my};
+                stack.push_back(ch);
+            }
+        }
+    }
+    return BH_OK;
+}
+
+int bh_export_tree(bh_ctx *c, bh_tree_node *nodes, int32_t *depth, int64_t cap, int64_t *n_nodes)
+{
+    if (!c || !n_nodes) return fail(c, BH_ERR_ARG, "bh_export_tree: null argument");
+    std::vector<bh_tree_node> out;
+    std::vector<int32_t> dep;
+    int rc = export_tree_host(c, out, dep);
+    if (rc) return rc;
+    *n_nodes = (int64_t)out.size();
+    if (!nodes || cap < (int64_t)out.size()) return fail(c, BH_ERR_CAPACITY, "bh_export_tree: buffer too small");
+    std::memcpy(nodes, out.data(), out.size() * sizeof(bh_tree_node));
+    if (depth) std::memcpy(depth, dep.data(), dep.size() * sizeof(int32_t));
+    return BH_OK;
+}
+
+int bh_write_quadtree_file(bh_ctx *c, const char *path)
+{
+    if (!c || !path) return fail(c, BH_ERR_ARG, "bh_write_quadtree_file: null argument");
+    std::vector<bh_tree_node> out;
+    std::vector<int32_t> dep;
+    int rc = export_tree_host(c, out, dep);
+    if (rc) return rc;
+    std::vector<double> pos(std::max<int64_t>(2 * c->n, 2));
+    rc = download_pairs(c, c->pos, pos.data(), 2 * c->n);
+    if (rc) return rc;
+    FILE *fp = std::fopen(path, "w");
+    if (!fp) return fail(c, BH_ERR_IO, std::string("cannot open ") + path);
+    for (size_t i = 0; i < out.size(); ++i) {
+        const bh_tree_node &q = out[i];
+        // `file << depth << " " << xmin ...` with the default ostream precision == "%g"
+        std::fprintf(fp, "%d %g %g %g %g %g", dep[i], q.xmin, q.xmax, q.ymin, q.ymax, q.mass);
+        const long long occ = (long long)q.particle;
+        if (occ != -1) {
+            const long long b = occ >= 0 ? occ : -(occ + 2);   // the reference reads out of bounds here
+            std::fprintf(fp, " occupantIndex=%lld occupantPos=(%g,%g)", occ, pos[2 * b], pos[2 * b + 1]);
+        } else if (q.mass > 0) {
+            std::fprintf(fp, " occupantIndex=%lld occupantPos=(%g,%g)", occ, q.comx, q.comy);
+        }
+        std::fputc('\n', fp);
+    }
+    std::fclose(fp);
+    return BH_OK;
+}
+
+int bh_stats(bh_ctx *c, bh_stats_t *out)
+{
+    if (!c || !out) return fail(c, BH_ERR_ARG, "bh_stats: null argument");
+    BH_HIP(c, hipSetDevice(c->device));
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+    std::memset(out, 0, sizeof(*out));
+    out->n_bodies = c->n;
+    out->steps_done = c->steps_done;
+    out->device_bytes = c->device_bytes;
+    if (c->tree_valid) {
+        TreeCounters h{};
+        BH_HIP(c, hipMemcpy(&h, c->ctr, sizeof(h), hipMemcpyDeviceToHost));
+        out->n_internal = h.n_internal;
+        out->n_nodes = 1 + 4 * (int64_t)h.n_internal;
+        out->visits = h.visits;
+        out->interactions = h.interactions;
+    }
+    if (c->step_timed) {
+        float ms = 0.f;
+        BH_HIP(c, hipEventElapsedTime(&ms, c->ev_step[0], c->ev_step[1]));
+        out->last_step_ms = (double)ms / std::max(1, c->last_nsteps);
+        BH_HIP(c, hipEventElapsedTime(&ms, c->ev_build[0], c->ev_build[1]));
+        out->build_ms = ms;
+        double acc = 0.0;
+        for (int s = 0; s < c->timed_pairs; ++s) {
+            BH_HIP(c, hipEventElapsedTime(&ms, c->ev[2 * s], c->ev[2 * s + 1]));
+            acc += ms;
+        }
+        out->walk_ms = c->timed_pairs ? acc / c->timed_pairs : 0.0;
+    }
+    return BH_OK;
+}
+
+// ---- multi-GPU plumbing -------------------------------------------------------------------------
+int bh_set_owned_fraction(bh_ctx *c, int32_t rank, int32_t world)
+{
+    if (!c || world < 1 || rank < 0 || rank >= world) return fail(c, BH_ERR_ARG, "bh_set_owned_fraction: bad rank/world");
+    c->rank = rank;
+    c->world = world;
+    return BH_OK;
+}
+
+int bh_owned_range(bh_ctx *c, int64_t *lo, int64_t *hi)
+{
+    if (!c || !lo || !hi) return BH_ERR_ARG;
+    owned_range(c, lo, hi);
+    return BH_OK;
+}
+
+int bh_device_state(bh_ctx *c, void **pos, void **vel, void **mass, int64_t *n, int32_t *elem_bytes)
+{
+    if (!c) return BH_ERR_ARG;
+    if (pos) *pos = c->pos;
+    if (vel) *vel = c->vel;
+    if (mass) *mass = c->mass;
+    if (n) *n = c->n;
+    if (elem_bytes) *elem_bytes = c->exact ? 8 : 4;
+    return BH_OK;
+}
+
+int bh_device_sorted(bh_ctx *c, void **sorted_pos, void **sorted_vel)
+{
+    if (!c) return BH_ERR_ARG;
+    if (c->exact) return fail(c, BH_ERR_STATE, "sorted exchange buffers exist in fp32 mode only");
+    if (sorted_pos) *sorted_pos = c->spos_out;
+    if (sorted_vel) *sorted_vel = c->svel;
+    return BH_OK;
+}
+
+}  // extern "C"
+
+namespace bh {
+__global__ __launch_bounds__(kBlock) void scatter_sorted_kernel(const uint32_t *__restrict__ perm,
+                                                                 const float2 *__restrict__ spos,
+                                                                 const float2 *__restrict__ svel,
+                                                                 float2 *__restrict__ pos,
+                                                                 float2 *__restrict__ vel, int64_t n)
+{
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t b = perm[s];
+    pos[b] = spos[s];
+    vel[b] = svel[s];
+}
+}  // namespace bh
+
+extern "C" {
+
+int bh_step_local(bh_ctx *c)
+{
+    if (!c) return BH_ERR_ARG;
+    if (!c->uploaded) return fail(c, BH_ERR_STATE, "bh_step_local before bh_upload");
+    if (c->exact) return fail(c, BH_ERR_STATE, "bh_step_local: fp32 mode only");
+    BH_HIP(c, hipSetDevice(c->device));
+    int rc = enqueue_build(c);
+    if (rc) return rc;
+    return enqueue_walk(c, true, true);
+}
+
+int bh_scatter_sorted(bh_ctx *c)
+{
+    if (!c) return BH_ERR_ARG;
+    if (c->exact) return fail(c, BH_ERR_STATE, "bh_scatter_sorted: fp32 mode only");
+    BH_HIP(c, hipSetDevice(c->device));
+    if (c->n > 0) {
+        hipLaunchKernelGGL(scatter_sorted_kernel, dim3(blocks_for(c->n, kBlock)), dim3(kBlock), 0, c->stream,
+                           c->perm, c->spos_out, c->svel, (float2 *)c->pos, (float2 *)c->vel, c->n);
+        BH_HIP(c, hipGetLastError());
+    }
+    c->steps_done += 1;
+    return BH_OK;
+}
+
+}  // extern "C"

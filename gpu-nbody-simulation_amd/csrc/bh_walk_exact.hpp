@@ -1,0 +1,122 @@
+// bh_walk_exact.hpp -- fp64 theta-walk that reproduces the reference's forces BIT FOR BIT, fused
+// with the integrator.  Replaces computeForces / computeForcesGpu (project.cu:593-675, 679-793)
+// and updateAccVelPos (project.cu:819-836).  Compiled with -ffp-contract=off.
+//
+// One wavefront walks the tree for 64 Morton-adjacent bodies (one body per lane).  The traversal
+// state is wave-uniform and lives in LDS: one entry per tree level = {first child of the quad,
+// 64-bit mask of the lanes that opened the parent, next child to visit}.  Children are visited
+// 3,2,1,0 -- the reference's pop order (it pushes 0..3 on a LIFO, project.cu:662-668) -- and a
+// child's whole subtree is finished before its sibling starts.  The wave therefore visits the
+// UNION of its lanes' private walks in the reference's DFS order, and each lane, masked to the
+// nodes its own walk would pop, adds its terms in exactly the reference's order: same fp64
+// operations, same order, same bits.  Node loads are wave-uniform (scalar loads), so a visit
+// costs one 40-byte read per wave instead of 64 divergent gathers.
+#pragma once
+
+#include "bh_tree.hpp"
+
+namespace bh {
+
+constexpr int kExactLevels = 34;   // max_depth <= 32 -> at most 32 stacked levels
+
+template <bool COMPAT, bool STATS>
+__global__ __launch_bounds__(kBlock) void walk_exact_kernel(
+    const NodeD *__restrict__ gd, const LinkD *__restrict__ ld, const uint32_t *__restrict__ perm,
+    double2 *__restrict__ pos, double2 *__restrict__ vel, const double *__restrict__ mass,
+    double2 *__restrict__ force_out, int64_t lo, int64_t hi, double theta, double G, double dt,
+    int integrate, TreeCounters *ctr)
+{
+    __shared__ int32_t s_quad[kWavesPerBlock][kExactLevels];
+    __shared__ int32_t s_next[kWavesPerBlock][kExactLevels];
+    __shared__ uint64_t s_mask[kWavesPerBlock][kExactLevels];
+
+    if (ctr->overflow) return;
+    const int w = wave_id(), lane = lane_id();
+    const int64_t s = lo + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = s < hi;
+    const int64_t body = valid ? (int64_t)perm[s] : -1;
+    const double2 p = valid ? pos[body] : double2{0.0, 0.0};
+    const double mi = valid ? mass[body] : 0.0;
+    const double Gm = G * mi;                      // (G * masses[i]) * nodeMass, project.cu:651
+    double fx = 0.0, fy = 0.0;
+    unsigned long long n_vis = 0, n_int = 0;
+
+    // evaluate one node for the lanes in `live`; returns the mask of lanes that must open it
+    auto visit = [&](int32_t node, uint64_t live, int32_t &child_out) -> uint64_t {
+        const NodeD q = gd[node];
+        const LinkD k = ld[node];
+        child_out = k.child;
+        if (q.m <= 1e-15) return 0;                // project.cu:617
+        const bool mine = (live >> lane) & 1ull;
+        const bool leaf = k.child < 0;             // all four children -1, project.cu:623-626
+        const double dx = q.cx - p.x;
+        const double dy = q.cy - p.y;
+        const double d2 = dx * dx + dy * dy;
+        const double d = sqrt(d2) + 1e-15;         // project.cu:634
+        const bool accept = leaf || (q.size / d < theta);   // project.cu:643
+        bool self = false;
+        if (leaf) {
+            self = ((int64_t)k.occ == body);
+            if (COMPAT) self = self || ((int64_t)k.occ + 2 == -body);   // project.cu:646
+        }
+        if (mine && accept && !self) {
+            const double f = (Gm * q.m) / d2;      // project.cu:651
+            const double ux = dx / d, uy = dy / d; // project.cu:654-655
+            fx += f * ux;
+            fy += f * uy;
+        }
+        if (STATS) {
+            n_vis += __popcll(live);
+            n_int += __popcll(__ballot(mine && accept && !self));
+        }
+        if (leaf) return 0;
+        return __ballot(mine && !accept);
+    };
+
+    int sp = -1;
+    {
+        int32_t child;
+        const uint64_t open = visit(0, __ballot(valid), child);
+        if (open != 0 && child >= 0) {
+            sp = 0;
+            if (lane == 0) { s_quad[w][0] = child; s_next[w][0] = 3; s_mask[w][0] = open; }
+        }
+    }
+    while (sp >= 0) {
+        // wave-uniform state (every lane reads the same LDS words)
+        const int32_t quad = __builtin_amdgcn_readfirstlane(s_quad[w][sp]);
+        const int32_t c = __builtin_amdgcn_readfirstlane(s_next[w][sp]);
+        if (c < 0) { --sp; continue; }
+        const uint64_t live = s_mask[w][sp];
+        if (lane == 0) s_next[w][sp] = c - 1;
+        int32_t child;
+        const uint64_t open = visit(quad + c, live, child);
+        if (open != 0 && child >= 0 && sp + 1 < kExactLevels) {
+            ++sp;
+            if (lane == 0) { s_quad[w][sp] = child; s_next[w][sp] = 3; s_mask[w][sp] = open; }
+        }
+    }
+
+    if (valid) {
+        force_out[body] = double2{fx, fy};
+        if (integrate) {
+            // updateAccVelPos, project.cu:827-834
+            const double ax = fx / mi, ay = fy / mi;
+            double2 v = vel[body];
+            v.x += ax * dt;  v.y += ay * dt;
+            vel[body] = v;
+            double2 np = p;
+            np.x += v.x * dt;  np.y += v.y * dt;
+            pos[body] = np;
+        }
+    }
+    if (STATS) {
+        // one atomic per wave
+        if (lane == 0) {
+            atomicAdd(&ctr->visits, n_vis);
+            atomicAdd(&ctr->interactions, n_int);
+        }
+    }
+}
+
+}  // namespace bh

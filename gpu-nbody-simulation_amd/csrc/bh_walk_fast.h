@@ -1,0 +1,31 @@
+// bh_walk_fast.h -- launcher interface of the fp32 walk (bh_walk_fast.hip is its own translation
+// unit so that it can be compiled with FMA contraction while the tree build and the exact walk
+// are compiled with -ffp-contract=off).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bh {
+
+struct NodeF;
+struct TreeCounters;
+
+struct WalkFastArgs {
+    const NodeF *nodes;
+    const float2 *spos;        // positions in Morton-sorted order
+    const float *smass;        // masses in sorted order (bucket leaves only)
+    const uint32_t *perm;      // sorted index -> caller index
+    float2 *pos, *vel;         // caller-order state (updated when integrate && !to_sorted)
+    float2 *spos_out, *svel;   // sorted-order outputs (integrate && to_sorted)
+    float2 *acc_out;           // caller-order accelerations, may be null
+    TreeCounters *ctr;
+    int64_t lo, hi;            // sorted range walked by this launch
+    float G, dt;
+    int integrate, to_sorted;
+};
+
+hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, bool buckets,
+                            hipStream_t st);
+
+}  // namespace bh

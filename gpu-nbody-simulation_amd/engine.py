@@ -1,0 +1,198 @@
+"""BarnesHutEngine: the Python face of one bh_ctx (include/bhgpu.h).
+
+Mirrors what runSimulationGpu (project.cu:918-1024) does with its device buffers, with the
+reference's compile-time constants (project.cu:1-11, 27-35, 60-62) as a runtime BhConfig.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+TREE_NODE_DTYPE = np.dtype(
+    [("child", "<f8", (4,)), ("comx", "<f8"), ("comy", "<f8"), ("mass", "<f8"), ("xmin", "<f8"),
+     ("xmax", "<f8"), ("ymin", "<f8"), ("ymax", "<f8"), ("particle", "<f8")])
+
+FLAG_WALK_STATS = 1 << 0
+FLAG_LDS_STACK = 1 << 1
+FLAG_NO_GRAPH = 1 << 2
+
+
+class Precision(enum.IntEnum):
+    F64_EXACT = 0   # bit-identical to the reference CPU path
+    F32 = 1         # throughput mode (BASELINE configs "fp32")
+
+
+class BhError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"bhgpu error {code}: {msg}")
+        self.code = code
+
+
+@dataclass
+class BhConfig:
+    capacity: int
+    theta: float = 0.5              # THETA, project.cu:60
+    G: float = 6.67e-11             # project.cu:27
+    dt: float = 1.0                 # DELTA_T, project.cu:29
+    max_depth: int = 10             # QUADTREE_MAX_DEPTH, project.cu:61
+    precision: Precision = Precision.F64_EXACT
+    reference_compat: bool = True
+    device: int = 0
+    n_threads: int = 0              # N_THREADS, project.cu:5-7 (accepted, not used)
+    flags: int = 0
+    node_capacity: int = 0
+
+
+@dataclass
+class BhStats:
+    n_bodies: int
+    n_nodes: int
+    n_internal: int
+    steps_done: int
+    visits: int
+    interactions: int
+    last_step_ms: float
+    build_ms: float
+    walk_ms: float
+    device_bytes: int
+
+
+def _dptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class BarnesHutEngine:
+    def __init__(self, cfg: BhConfig):
+        self._lib = _lib.load()
+        self.cfg = cfg
+        c = _lib.bh_config(cfg.capacity, cfg.theta, cfg.G, cfg.dt, cfg.max_depth, int(cfg.precision),
+                           1 if cfg.reference_compat else 0, cfg.device, cfg.n_threads, cfg.flags,
+                           cfg.node_capacity)
+        h = C.c_void_p()
+        rc = self._lib.bh_create(C.byref(c), C.byref(h))
+        if rc != 0:
+            raise BhError(rc, (self._lib.bh_last_error(None) or b"").decode())
+        self._h = h
+        self.n = 0
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise BhError(rc, (self._lib.bh_last_error(self._h) or b"").decode())
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.bh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- state ------------------------------------------------------------------------------
+    def upload(self, positions, velocities, masses) -> None:
+        pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 2)
+        vel = np.ascontiguousarray(velocities, dtype=np.float64).reshape(-1, 2)
+        m = np.ascontiguousarray(masses, dtype=np.float64).reshape(-1)
+        if not (len(pos) == len(vel) == len(m)):
+            raise ValueError("positions, velocities and masses must have the same length")
+        self._check(self._lib.bh_upload(self._h, _dptr(pos), _dptr(vel), _dptr(m), len(m)))
+        self.n = len(m)
+
+    def download(self):
+        pos = np.empty((self.n, 2))
+        vel = np.empty((self.n, 2))
+        self._check(self._lib.bh_download(self._h, _dptr(pos), _dptr(vel)))
+        return pos, vel
+
+    # -- hot path ---------------------------------------------------------------------------
+    def step(self, nsteps: int = 1) -> None:
+        self._check(self._lib.bh_step(self._h, nsteps))
+
+    def sync(self) -> None:
+        self._check(self._lib.bh_sync(self._h))
+
+    def build_tree(self) -> None:
+        self._check(self._lib.bh_build_tree(self._h))
+
+    def compute_forces(self) -> np.ndarray:
+        self._check(self._lib.bh_compute_forces(self._h))
+        return self.forces()
+
+    def forces(self) -> np.ndarray:
+        f = np.empty((self.n, 2))
+        self._check(self._lib.bh_get_forces(self._h, _dptr(f)))
+        return f
+
+    def accelerations(self) -> np.ndarray:
+        a = np.empty((self.n, 2))
+        self._check(self._lib.bh_get_accel(self._h, _dptr(a)))
+        return a
+
+    # -- tree output ------------------------------------------------------------------------
+    def export_tree(self):
+        """(nodes in DFS pre-order as TREE_NODE_DTYPE, depth)."""
+        n = C.c_int64(0)
+        rc = self._lib.bh_export_tree(self._h, None, None, 0, C.byref(n))
+        if rc not in (0, -4):
+            self._check(rc)
+        nodes = np.zeros(max(n.value, 1), dtype=TREE_NODE_DTYPE)
+        depth = np.zeros(max(n.value, 1), dtype=np.int32)
+        self._check(self._lib.bh_export_tree(self._h, nodes.ctypes.data,
+                                             depth.ctypes.data_as(C.POINTER(C.c_int32)), len(nodes),
+                                             C.byref(n)))
+        return nodes[: n.value], depth[: n.value]
+
+    def write_quadtree_file(self, path: str) -> None:
+        self._check(self._lib.bh_write_quadtree_file(self._h, os.fsencode(path)))
+
+    # -- measurement ------------------------------------------------------------------------
+    def stats(self) -> BhStats:
+        s = _lib.bh_stats_t()
+        self._check(self._lib.bh_stats(self._h, C.byref(s)))
+        return BhStats(s.n_bodies, s.n_nodes, s.n_internal, s.steps_done, s.visits, s.interactions,
+                       s.last_step_ms, s.build_ms, s.walk_ms, s.device_bytes)
+
+    # -- multi-GPU plumbing -----------------------------------------------------------------
+    def set_owned_fraction(self, rank: int, world: int) -> None:
+        self._check(self._lib.bh_set_owned_fraction(self._h, rank, world))
+
+    def owned_range(self):
+        lo, hi = C.c_int64(), C.c_int64()
+        self._check(self._lib.bh_owned_range(self._h, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def step_local(self) -> None:
+        self._check(self._lib.bh_step_local(self._h))
+
+    def scatter_sorted(self) -> None:
+        self._check(self._lib.bh_scatter_sorted(self._h))
+
+    def device_sorted(self):
+        p, v = C.c_void_p(), C.c_void_p()
+        self._check(self._lib.bh_device_sorted(self._h, C.byref(p), C.byref(v)))
+        return p.value, v.value
+
+    def device_state(self):
+        p, v, m = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n, eb = C.c_int64(), C.c_int32()
+        self._check(self._lib.bh_device_state(self._h, C.byref(p), C.byref(v), C.byref(m), C.byref(n),
+                                              C.byref(eb)))
+        return p.value, v.value, m.value, n.value, eb.value
+
+    def set_stream(self, hip_stream: int) -> None:
+        self._check(self._lib.bh_set_stream(self._h, C.c_void_p(hip_stream)))

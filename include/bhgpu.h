@@ -1,0 +1,175 @@
+/*
+ * bhgpu.h -- C-ABI of libbhgpu.so, the MI355X-native Barnes-Hut step.
+ *
+ * The reference (DavidSevic/gpu-nbody-simulation) has NO library interface: its three
+ * programs are configured by -D macros and by editing source (README.md:9-18), and the only
+ * stable contract is file level.  This header is therefore the boundary a
+ * maintainer would bind instead of calling runSimulationGpu() (project.cu:918-1024): each
+ * entry point cites the reference function(s) it replaces.  Paths are relative to
+ * /root/reference/implementation/.  INTEGRATION.md shows the ctypes stub and the three-line
+ * change to a C++ main().
+ *
+ * Conventions
+ *   - plain C types only; every call returns 0 on success or a negative bh_status;
+ *     bh_last_error(ctx) gives the text.  No exceptions cross the boundary.
+ *   - the caller owns every host buffer; the library owns all device memory.
+ *   - host arrays use the reference's layout: positions/velocities AoS double[n][2],
+ *     masses double[n] (project.cu:38-43).  Body order is the caller's order on every
+ *     download, whatever order the device keeps internally.
+ *   - one context per device; a context is not thread-safe; there are no globals.
+ */
+#ifndef BHGPU_H
+#define BHGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BHGPU_ABI_VERSION 1
+
+typedef enum bh_status {
+    BH_OK = 0,
+    BH_ERR_ARG = -1,         /* bad argument (null pointer, n > capacity, ...)            */
+    BH_ERR_DEVICE = -2,      /* HIP runtime error; text in bh_last_error                  */
+    BH_ERR_NO_DEVICE = -3,   /* no usable GPU: the product has no CPU fallback            */
+    BH_ERR_CAPACITY = -4,    /* tree needs more nodes than node_capacity                  */
+    BH_ERR_STATE = -5,       /* call order (e.g. step before upload)                      */
+    BH_ERR_IO = -6           /* cannot open/write a file                                  */
+} bh_status;
+
+typedef enum bh_precision {
+    /* fp64 state, fp64 arithmetic in the reference's operation order, no FMA contraction:
+     * results are bit-identical to the reference CPU path (project.cu:865-916). */
+    BH_PRECISION_F64_EXACT = 0,
+    /* fp32 state and arithmetic (BASELINE config "fp32"): the throughput mode. */
+    BH_PRECISION_F32 = 1
+} bh_precision;
+
+/* bh_config.flags */
+#define BH_FLAG_WALK_STATS   (1u << 0)  /* count visits/interactions in the walk (slower)   */
+#define BH_FLAG_LDS_STACK    (1u << 1)  /* fp32 walk: LDS traversal stack instead of the
+                                           register-lane stack (A/B switch)  */
+#define BH_FLAG_NO_GRAPH     (1u << 2)  /* launch kernels eagerly instead of via hipGraph    */
+
+/* Replaces the compile-time configuration of project.cu:1-11, 27-35, 60-62. */
+typedef struct bh_config {
+    int64_t  capacity;          /* max bodies (N_BODIES, project.cu:1-3)                    */
+    double   theta;             /* THETA, project.cu:60 (0.5)                               */
+    double   G;                 /* project.cu:27 (6.67e-11)                                 */
+    double   dt;                /* DELTA_T, project.cu:29 (1.0)                             */
+    int32_t  max_depth;         /* QUADTREE_MAX_DEPTH, project.cu:61 (10); root is depth 1;
+                                   1..32                                                    */
+    int32_t  precision;         /* bh_precision                                             */
+    int32_t  reference_compat;  /* 1: depth-cap aggregation and the `occ+2 == -i` self skip
+                                   exactly as project.cu:360-382, 646 (self-interaction
+                                   artefact included).  0: a depth-cap cell holding several
+                                   bodies is still one aggregate node, but a body never
+                                   interacts with a node that contains only itself.         */
+    int32_t  device;            /* HIP device ordinal                                       */
+    int32_t  n_threads;         /* N_THREADS, project.cu:5-7.  Accepted so the scaling
+                                   scripts' parameter has somewhere to go; the CDNA4 launch
+                                   shape does not depend on it (a12 is replaced, not kept).  */
+    uint32_t flags;             /* BH_FLAG_*                                                */
+    int64_t  node_capacity;     /* 0 = automatic (8*capacity + 1024 nodes)                  */
+} bh_config;
+
+/* The reference's 12-double `Quadrant` (project.cu:46-65), as exported by bh_export_tree.
+ * child[k] is an index INTO THE EXPORTED ARRAY (DFS pre-order), or -1. */
+typedef struct bh_tree_node {
+    double child[4];
+    double comx, comy, mass;
+    double xmin, xmax, ymin, ymax;
+    double particle;
+} bh_tree_node;
+
+typedef struct bh_stats_t {
+    int64_t  n_bodies;
+    int64_t  n_nodes;            /* nodes of the last tree built                            */
+    int64_t  n_internal;         /* subdivided cells of the last tree                       */
+    int64_t  steps_done;
+    uint64_t visits;             /* BH_FLAG_WALK_STATS: body-node visits of the last walk   */
+    uint64_t interactions;       /* BH_FLAG_WALK_STATS: accepted force evaluations          */
+    double   last_step_ms;       /* HIP-event time of the last bh_step call / nsteps        */
+    double   build_ms;           /* bounds+keys+sort+nodes+COM of the last timed step       */
+    double   walk_ms;            /* walk+integrate kernel of the last timed step            */
+    uint64_t device_bytes;       /* device memory held by the context                       */
+} bh_stats_t;
+
+typedef struct bh_ctx bh_ctx;
+
+/* --- lifetime ---------------------------------------------------------------------------
+ * Replaces the cudaMalloc block of runSimulationGpu (project.cu:932-940) and its cudaFree
+ * block (:1014-1019).  Fails with BH_ERR_NO_DEVICE when no GPU is present. */
+int bh_create(const bh_config *cfg, bh_ctx **out);
+void bh_destroy(bh_ctx *ctx);
+/* ctx may be NULL: then the text of the last failed bh_create on this thread. */
+const char *bh_last_error(const bh_ctx *ctx);
+int bh_abi_version(void);
+
+/* --- state ------------------------------------------------------------------------------
+ * bh_upload replaces the three cudaMemcpy H2D of project.cu:943-945 (and, on the caller's
+ * side, the arrays filled by loadSimulationDataFromText, project.cu:103-161).
+ * bh_download replaces the per-step D2H of positions (project.cu:1010) and additionally
+ * returns velocities, which the reference never exposes.  vel may be NULL. */
+int bh_upload(bh_ctx *ctx, const double *pos, const double *vel, const double *mass, int64_t n);
+int bh_download(bh_ctx *ctx, double *pos, double *vel);
+
+/* --- the hot path -----------------------------------------------------------------------
+ * bh_step: nsteps x { buildTree (project.cu:575-591), computeForcesGpu (:679-793),
+ * updateAccVelPos (:819-836) }, i.e. the body of the step loop project.cu:955-1011, with
+ * the tree built on the device instead of the host.  Asynchronous on the context's stream;
+ * bh_sync / bh_download / bh_stats wait for it. */
+int bh_step(bh_ctx *ctx, int32_t nsteps);
+int bh_sync(bh_ctx *ctx);
+
+/* The same three stages one at a time, for per-stage parity checks:
+ * bh_build_tree   = buildTree            (project.cu:575-591)
+ * bh_compute_forces = buildTree + computeForces/computeForcesGpu (project.cu:593-675, 679-793);
+ *                   state is not advanced
+ * bh_get_forces   -> forces[n][2], FORCE with m_i included as in the reference's `forces`
+ * bh_get_accel    -> forces / m_i (updateAccelerations, project.cu:795-801)               */
+int bh_build_tree(bh_ctx *ctx);
+int bh_compute_forces(bh_ctx *ctx);
+int bh_get_forces(bh_ctx *ctx, double *forces);
+int bh_get_accel(bh_ctx *ctx, double *accel);
+
+/* --- tree output ------------------------------------------------------------------------
+ * bh_export_tree: the tree of the last bh_build_tree/bh_compute_forces/bh_step in DFS
+ * pre-order with children in index order -- the visiting order of TraverseTreeToFile
+ * (project.cu:504-534).  depth may be NULL.  *n_nodes receives the node count even when cap
+ * is too small (then BH_ERR_CAPACITY).
+ * bh_write_quadtree_file: TraverseTreeToFile itself (same text format, project.cu:509-526);
+ * for occupant indices <= -2, where the reference reads out of bounds, the body's true
+ * position is printed. */
+int bh_export_tree(bh_ctx *ctx, bh_tree_node *nodes, int32_t *depth, int64_t cap,
+                   int64_t *n_nodes);
+int bh_write_quadtree_file(bh_ctx *ctx, const char *path);
+
+/* --- measurement (replaces the std::chrono timers of project.cu:985-1007) ----------------*/
+int bh_stats(bh_ctx *ctx, bh_stats_t *out);
+
+/* --- multi-GPU plumbing -----------------------------------------------------------------
+ * The reference is single-GPU.  One process per GPU owns a contiguous range [lo, hi) of
+ * the Morton-sorted bodies: bh_step then walks and integrates only that range, and the
+ * host exchanges the updated ranges (torch.distributed all_gather over RCCL) through the
+ * device pointers below.  Pointers stay valid until bh_destroy; element types follow the
+ * context's precision (double2/double or float2/float). */
+int bh_set_owned_fraction(bh_ctx *ctx, int32_t rank, int32_t world);
+int bh_device_state(bh_ctx *ctx, void **pos, void **vel, void **mass, int64_t *n,
+                    int32_t *elem_bytes);
+int bh_owned_range(bh_ctx *ctx, int64_t *lo, int64_t *hi);
+/* Sorted-order views used by the exchange: after bh_step_local the owned slice of
+ * sorted_pos/sorted_vel holds the new state; bh_scatter_sorted writes the full sorted
+ * arrays (after the all_gather) back to caller order. */
+int bh_step_local(bh_ctx *ctx);
+int bh_device_sorted(bh_ctx *ctx, void **sorted_pos, void **sorted_vel);
+int bh_scatter_sorted(bh_ctx *ctx);
+/* Run on an external HIP stream (e.g. torch's current stream), passed as void*. */
+int bh_set_stream(bh_ctx *ctx, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BHGPU_H */
