@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- body-steps/s of the Barnes-Hut step on MI355X (contract: see the task statement).
+
+    python bench.py                       # N=1 GPU, defaults finish in a couple of minutes
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over all bodies: root box -> keys -> radix sort -> tree
+nodes/COM -> theta-walk -> integrate, all on the device, bodies resident in HBM before the timed
+region.  Workload = BASELINE.json's metric configuration: N = 1,048,576 bodies, theta = 0.5,
+Plummer sphere (configs[2]), fp32.  With --gpus N the SAME bodies are split over N ranks
+(strong scaling), one all_gather per step over RCCL.
+
+One JSON line on stdout (rank 0).  Besides the contract's fields it carries
+  roofline     : the walk kernel's algorithmic bytes / its HIP-event time vs the 8 TB/s HBM peak
+  cpu_baseline : the oracle (a port of the reference's CPU path) timed on this host, 1 core,
+                 one full step of the same workload
+  minteractions_per_s : the metric's second half (accepted body-node force evaluations / s)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+NODE_BYTES = 32         # fp32 node record (bh_nodes.hpp NodeF)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-bodies", type=int, default=1 << 20)
+    ap.add_argument("--init", choices=["plummer", "uniform"], default="plummer")
+    ap.add_argument("--theta", type=float, default=0.5)
+    ap.add_argument("--max-depth", type=int, default=21)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--lds-stack", action="store_true", help="A/B: LDS traversal stack variant")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="bodies walked by the CPU baseline (0 = all, i.e. one full step)")
+    return ap.parse_args()
+
+
+def cpu_baseline(mass, pos, theta, sample):
+    """The oracle (port of project.cu:575-675 / main_approach_2.cpp, uncapped tree) on ONE core:
+    one tree build over all bodies + the walk of `sample` bodies, scaled to body-steps/s."""
+    from oracle import bh_oracle as O
+    n = len(mass)
+    sample = n if sample <= 0 else min(sample, n)
+    t0 = time.perf_counter()
+    tree = O.build_tree(pos, mass, 0)
+    t1 = time.perf_counter()
+    f, st = O.compute_forces(tree, pos, mass, theta=theta, compat_self_skip=False, lo=0, hi=sample,
+                             with_stats=True)
+    t2 = time.perf_counter()
+    build_s, walk_s = t1 - t0, t2 - t1
+    est_step = build_s + walk_s * n / sample
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {
+        "value": n / est_step, "unit": "body-steps/s", "cores": 1, "kind": "port",
+        "sample": (f"one step at N={n}: full tree build ({build_s:.2f} s) + theta-walk of {sample} bodies "
+                   f"({walk_s:.2f} s)" + ("" if sample == n else ", walk scaled to N")),
+        "force_update_only_body_steps_per_s": sample / walk_s,
+        "minteractions_per_s": st.interactions / walk_s / 1e6,
+        "interactions_per_body": st.interactions / sample,
+        "cpu_model": model,
+    }
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    import gpu_nbody_simulation_amd as G
+    from gpu_nbody_simulation_amd import initial_conditions as IC
+    from gpu_nbody_simulation_amd.distributed import ShardedStepper, init_process_group_from_env
+    from gpu_nbody_simulation_amd.engine import FLAG_LDS_STACK, FLAG_WALK_STATS
+
+    rank, local, world = init_process_group_from_env("nccl")
+    if world != a.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        a.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    n = a.n_bodies
+    mass, pos, vel = IC.make(a.init, n, a.seed, quasi_static=True)
+    flags = FLAG_LDS_STACK if a.lds_stack else 0
+    cfg = G.BhConfig(capacity=n, theta=a.theta, max_depth=a.max_depth, precision=G.Precision.F32,
+                     reference_compat=False, device=local, flags=flags)
+    eng = G.BarnesHutEngine(cfg)
+    if world > 1:
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.upload(pos, vel, mass)                       # bodies resident in HBM from here on
+    stepper = ShardedStepper(eng, rank, world, n, dev)
+
+    def sync_all():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        stepper.step()
+    sync_all()
+    t0 = time.perf_counter()
+    if world == 1:
+        eng.step(a.steps)                            # K steps enqueued back to back on one stream
+    else:
+        for _ in range(a.steps):
+            stepper.step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    st = eng.stats()                                 # HIP events recorded inside the timed region
+    walk_ms = st.walk_ms if world == 1 else None
+
+    # ---- untimed: counters of one walk on the final state (second engine, stats variant) --------
+    pf, vf = eng.download()
+    out = None
+    if rank == 0:
+        with G.BarnesHutEngine(G.BhConfig(capacity=n, theta=a.theta, max_depth=a.max_depth,
+                                          precision=G.Precision.F32, reference_compat=False, device=local,
+                                          flags=flags | FLAG_WALK_STATS)) as se:
+            se.upload(pf, vf, mass)
+            se.compute_forces()
+            ss = se.stats()
+        u64 = ss.wave_nodes / n                      # distinct nodes per body per 64-body group
+        # algorithmic bytes of ONE walk+integrate launch (DESIGN.md "Roofline"):
+        #   per body: sorted pos 8 + perm 4 + vel r/w 16 + pos w 8 + accel w 8 = 44 B
+        #   per wave-node visit: one 32-byte node record
+        walk_bytes = n * 44 + ss.wave_nodes * NODE_BYTES
+        value = n * a.steps / elapsed
+        roof = None
+        if walk_ms:
+            ach = walk_bytes / (walk_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "walk_fast_kernel", "kernel_ms": walk_ms,
+                    "algorithmic_bytes_per_launch": walk_bytes, "u64_nodes_per_body": u64}
+        out = {
+            "metric": "body-steps/sec", "value": value, "unit": "body-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.init}_N{n}_theta{a.theta}", "n_bodies": n, "theta": a.theta,
+                       "max_depth": a.max_depth, "init": a.init, "seed": a.seed,
+                       "parallelism": "1 GPU" if world == 1 else f"morton-range x{world}, all_gather/step"},
+            "minteractions_per_s": ss.interactions * a.steps / elapsed / 1e6,
+            "interactions_per_body": ss.interactions / n,
+            "build_ms": st.build_ms, "walk_ms": st.walk_ms, "n_nodes": ss.n_nodes,
+            "roofline": roof,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(mass, pos, a.theta, a.cpu_sample)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        else:
+            out["cpu_baseline"] = None
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

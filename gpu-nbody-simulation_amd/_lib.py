@@ -39,6 +39,7 @@ class bh_stats_t(C.Structure):
     _fields_ = [
         ("n_bodies", C.c_int64), ("n_nodes", C.c_int64), ("n_internal", C.c_int64),
         ("steps_done", C.c_int64), ("visits", C.c_uint64), ("interactions", C.c_uint64),
+        ("wave_nodes", C.c_uint64),
         ("last_step_ms", C.c_double), ("build_ms", C.c_double), ("walk_ms", C.c_double),
         ("device_bytes", C.c_uint64),
     ]

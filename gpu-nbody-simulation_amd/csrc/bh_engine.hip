@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "bh_tree.hpp"
@@ -111,8 +112,11 @@ inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + pe
 
 void owned_range(const bh_ctx *c, int64_t *lo, int64_t *hi)
 {
-    *lo = c->n * c->rank / c->world;
-    *hi = c->n * (c->rank + 1) / c->world;
+    // equal chunks of ceil(n/world) sorted slots (the last ranks may own fewer, or none), so the
+    // all_gather of the exchange moves one fixed-size block per rank
+    const int64_t chunk = (c->n + c->world - 1) / c->world;
+    *lo = std::min<int64_t>(c->n, chunk * c->rank);
+    *hi = std::min<int64_t>(c->n, chunk * (c->rank + 1));
 }
 
 // exclusive scan of `len` uint32 in place; total (if non-null) receives the sum
@@ -194,12 +198,17 @@ int enqueue_build_t(bh_ctx *c)
     }
 
     // 6. nodes
-    hipLaunchKernelGGL((root_only_kernel<EXACT, Real2, Real>), dim3(1), dim3(64), 0, st, pos, mass, c->perm,
-                       c->box, n, Dm, c->cfg.theta, c->gd, c->ld, c->nf, c->ctr);
+    auto launch_nodes = [&](auto compat_tag) {
+        constexpr bool CP = decltype(compat_tag)::value;
+        hipLaunchKernelGGL((root_only_kernel<EXACT, CP, Real2, Real>), dim3(1), dim3(64), 0, st, pos, mass, c->perm,
+                           c->box, n, Dm, c->cfg.theta, c->gd, c->ld, c->nf, c->ctr);
+        if (n > 1)
+            hipLaunchKernelGGL((nodes_kernel<EXACT, CP, Real2, Real>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st,
+                               c->keys_sorted, c->perm, c->cnt, pos, mass, c->box, c->terms, n, Dm, c->cfg.theta,
+                               c->internal_cap, c->gd, c->ld, c->nf, c->self_node, c->cell_depth, c->ctr);
+    };
+    if (c->compat || EXACT) launch_nodes(std::true_type{}); else launch_nodes(std::false_type{});
     if (n > 1) {
-        hipLaunchKernelGGL((nodes_kernel<EXACT, Real2, Real>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st,
-                           c->keys_sorted, c->perm, c->cnt, pos, mass, c->box, c->terms, n, Dm, c->cfg.theta,
-                           c->internal_cap, c->gd, c->ld, c->nf, c->self_node, c->cell_depth, c->ctr);
         // 7. exact bottom-up mass pass (ComputeMass, project.cu:473-502)
         if (EXACT) {
             const int64_t span = std::min<int64_t>(c->internal_cap, std::max<int64_t>(1, (n - 1) * (int64_t)std::max(1, Dm)));
@@ -240,8 +249,9 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted)
         a.acc_out = (float2 *)c->force; a.ctr = c->ctr;
         a.lo = lo; a.hi = hi; a.G = (float)c->cfg.G; a.dt = (float)c->cfg.dt;
         a.integrate = integrate ? 1 : 0; a.to_sorted = to_sorted ? 1 : 0;
-        const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0 || (3 * c->Dm + 4 > kWave);
-        BH_HIP(c, launch_walk_fast(a, lds, stats, !c->compat, c->stream));
+        // the register-lane stack holds 64 entries; the walk never needs more than 3*Dm + 2
+        const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0 || (3 * c->Dm + 2 > kWave);
+        BH_HIP(c, launch_walk_fast(a, lds, stats, c->stream));
     }
     return BH_OK;
 }
@@ -327,7 +337,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
         A(&c->self_node, c->internal_cap + 1); A(&c->cell_depth, c->internal_cap + 1);
     } else {
         A(&c->nf, c->node_cap);
-        A(&c->spos, cap); A(&c->spos_out, cap); A(&c->svel, cap); A(&c->smass, cap);
+        A(&c->spos, cap); A(&c->spos_out, cap + 1024); A(&c->svel, cap + 1024); A(&c->smass, cap);
         A(&c->terms, cap + 1); A(&c->bsum_d3, blocks_for(cap + 1, kTile) + 8);
     }
     if (rc) return bail(rc);
@@ -547,8 +557,8 @@ static int export_tree_host(bh_ctx *c, std::vector<bh_tree_node> &out, std::vect
             const NodeF &f = nf[it.node];
             q.comx = f.cx; q.comy = f.cy; q.mass = f.m;
             child = f.child;
-            if (f.occ >= 0) {
-                const int64_t body = perm[f.occ];
+            if (f.child < 0 && f.count == 1) {     // single occupant: the reference's PARTICLE_INDEX
+                const int64_t body = perm[f.first];
                 q.particle = (it.depth == c->Dm) ? (double)(-body - 2) : (double)body;
             } else q.particle = -1.0;
         }
@@ -630,6 +640,7 @@ int bh_stats(bh_ctx *c, bh_stats_t *out)
         out->n_nodes = 1 + 4 * (int64_t)h.n_internal;
         out->visits = h.visits;
         out->interactions = h.interactions;
+        out->wave_nodes = h.wave_nodes;
     }
     if (c->step_timed) {
         float ms = 0.f;

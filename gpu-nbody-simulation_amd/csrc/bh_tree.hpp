@@ -154,7 +154,7 @@ __device__ __forceinline__ int64_t lower_bound_prefix(const uint64_t *__restrict
 }
 
 // ---- root record when nothing is subdivided (n <= 1, or max_depth == 1) ------------------------
-template <bool EXACT, typename Real2, typename Real>
+template <bool EXACT, bool COMPAT, typename Real2, typename Real>
 __global__ void root_only_kernel(const Real2 *__restrict__ pos, const Real *__restrict__ mass,
                                  const uint32_t *__restrict__ perm, const double *__restrict__ box,
                                  int64_t n, int Dm, double theta, NodeD *gd, LinkD *ld, NodeF *nf,
@@ -186,7 +186,8 @@ __global__ void root_only_kernel(const Real2 *__restrict__ pos, const Real *__re
     } else {
         NodeF r;
         r.cx = (float)cx; r.cy = (float)cy; r.m = (float)m; r.thr = -1.0f;
-        r.child = -1; r.occ = occ; r.first = 0; r.count = (int32_t)n;
+        r.child = -1; r.first = 0; r.count = (m > 1e-15) ? (int32_t)n : 0; r.pad = 0;
+        if (n > 1 && !COMPAT) { r.child = -2; r.thr = INFINITY; }     // root itself is a bucket
         nf[0] = r;
     }
 }
@@ -194,7 +195,7 @@ __global__ void root_only_kernel(const Real2 *__restrict__ pos, const Real *__re
 // ---- nodes: the owner of each subdivided cell writes its four children --------------------------
 // EXACT: NodeD/LinkD + self_node/cell_depth for the bottom-up pass.
 // !EXACT: NodeF complete (COM from the fp64 prefix sums psum[0..n], psum[j] = sum over sorted < j).
-template <bool EXACT, typename Real2, typename Real>
+template <bool EXACT, bool COMPAT, typename Real2, typename Real>
 __global__ __launch_bounds__(kBlock) void nodes_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm,
     const uint32_t *__restrict__ off, const Real2 *__restrict__ pos, const Real *__restrict__ mass,
@@ -253,7 +254,8 @@ __global__ __launch_bounds__(kBlock) void nodes_kernel(
                 rt.m = (float)t.a; rt.cx = (float)(t.b / t.a); rt.cy = (float)(t.c / t.a);
                 const double q = size * inv_theta;
                 rt.thr = (float)(q * q);
-                rt.child = quad; rt.occ = -1; rt.first = 0; rt.count = (int32_t)n;
+                rt.child = quad; rt.first = 0; rt.count = (int32_t)n; rt.pad = 0;
+                if (!(t.a > 1e-15)) { rt.child = -1; rt.count = 0; }
                 nf[0] = rt;
             }
         }
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(kBlock) void nodes_kernel(
             const int32_t node = quad + c;
             double m = 0.0, cx = 0.0, cy = 0.0;
             int32_t child = -1, occ = -1;
-            bool internal = false;
+            bool internal = false, bucket = false;
             if (nc == 0) {
                 // empty leaf: blank child of project.cu:422-428
             } else if (d + 1 == Dm) {
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(kBlock) void nodes_kernel(
                     if (nc == 1) { const uint32_t bi = perm[bc]; cx = (double)pos[bi].x; cy = (double)pos[bi].y; m = (double)mass[bi]; }
                     else { cx = (hi_s.b - lo_s.b) / m; cy = (hi_s.c - lo_s.c) / m; }
                     occ = (nc == 1) ? (int32_t)bc : -1;
+                    bucket = (nc > 1) && !COMPAT;
                 }
             } else if (nc == 1) {
                 // single body in an undivided cell, project.cu:398-406
@@ -315,8 +318,10 @@ __global__ __launch_bounds__(kBlock) void nodes_kernel(
                 NodeF q;
                 q.cx = (float)cx; q.cy = (float)cy; q.m = (float)m;
                 if (internal) { const double s = size * inv_theta; q.thr = (float)(s * s); }
+                else if (bucket) { q.thr = INFINITY; child = -node - 2; }
                 else q.thr = -1.0f;
-                q.child = child; q.occ = occ; q.first = (int32_t)bc; q.count = (int32_t)nc;
+                q.child = child; q.first = (int32_t)bc; q.count = (int32_t)nc; q.pad = 0;
+                if (nc > 0 && !(m > 1e-15)) { q.child = -1; q.count = 0; q.thr = -1.0f; }
                 nf[node] = q;
             }
         }

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
     const double mi = valid ? mass[body] : 0.0;
     const double Gm = G * mi;                      // (G * masses[i]) * nodeMass, project.cu:651
     double fx = 0.0, fy = 0.0;
-    unsigned long long n_vis = 0, n_int = 0;
+    unsigned long long n_vis = 0, n_int = 0, n_wave = 0;
 
     // evaluate one node for the lanes in `live`; returns the mask of lanes that must open it
     auto visit = [&](int32_t node, uint64_t live, int32_t &child_out) -> uint64_t {
@@ -67,6 +67,7 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
         }
         if (STATS) {
             n_vis += __popcll(live);
+            ++n_wave;
             n_int += __popcll(__ballot(mine && accept && !self));
         }
         if (leaf) return 0;
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
         if (lane == 0) {
             atomicAdd(&ctr->visits, n_vis);
             atomicAdd(&ctr->interactions, n_int);
+            atomicAdd(&ctr->wave_nodes, n_wave);
         }
     }
 }

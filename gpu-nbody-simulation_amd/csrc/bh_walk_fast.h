@@ -25,7 +25,6 @@ struct WalkFastArgs {
     int integrate, to_sorted;
 };
 
-hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, bool buckets,
-                            hipStream_t st);
+hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, hipStream_t st);
 
 }  // namespace bh

@@ -16,7 +16,8 @@
 //   * MAC per body exactly as the reference's (size/dist < theta, evaluated per lane), in the
 //     algebraically equal form d2 > (size/theta)^2 with the right side precomputed per node.
 //   * force per accepted node: G*M*d/(|d|^3) through v_rsq_f32; the reference's 1e-15 offset on
-//     dist (project.cu:634) is below fp32 resolution and omitted.
+//     dist (project.cu:634) is below fp32 resolution and omitted; a node at distance exactly 0
+//     (the body itself, or an exactly coincident body) contributes nothing.
 //   * epilogue: a = G*sum, v += a*dt, p += v*dt written back in caller order (scatter through
 //     perm), or into the sorted arrays for the multi-GPU exchange.
 #include "bh_prims.hpp"
@@ -41,6 +42,7 @@ __device__ __forceinline__ const T BH_CONSTANT *as_constant(const T *p)
 
 // one 32-byte node through the scalar data cache (s_load_dwordx8): the address is wave-uniform
 typedef int32_t v8i __attribute__((ext_vector_type(8)));
+typedef int32_t v2i __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ NodeF load_node(const NodeF BH_CONSTANT *p)
 {
 #pragma clang diagnostic push
@@ -50,13 +52,34 @@ __device__ __forceinline__ NodeF load_node(const NodeF BH_CONSTANT *p)
     NodeF q;
     q.cx = __int_as_float(r[0]); q.cy = __int_as_float(r[1]);
     q.m = __int_as_float(r[2]);  q.thr = __int_as_float(r[3]);
-    q.child = r[4]; q.occ = r[5]; q.first = r[6]; q.count = r[7];
+    q.child = r[4]; q.first = r[5]; q.count = r[6]; q.pad = r[7];
     return q;
+}
+
+typedef int32_t v32i __attribute__((ext_vector_type(32)));
+__device__ __forceinline__ void load_quad(const NodeF BH_CONSTANT *p, NodeF (&q)[4])
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    const v32i r = *(const v32i BH_CONSTANT *)p;
+#pragma clang diagnostic pop
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        q[k].cx = __int_as_float(r[8 * k + 0]); q[k].cy = __int_as_float(r[8 * k + 1]);
+        q[k].m = __int_as_float(r[8 * k + 2]);  q[k].thr = __int_as_float(r[8 * k + 3]);
+        q[k].child = r[8 * k + 4]; q[k].first = r[8 * k + 5]; q[k].count = r[8 * k + 6];
+        q[k].pad = r[8 * k + 7];
+    }
 }
 
 constexpr int kLdsStackDepth = 128;   // 3*31+4 entries worst case
 
-template <bool LDS_STACK, bool STATS, bool BUCKETS>
+// The loop body is written so that hipcc emits straight-line code per child: the push is an
+// unconditional write of {child, open mask} into the slot above the top followed by
+// `sp += (open != 0)`, so there is no control-flow merge (and none of the register copies it
+// costs) around the stack registers; lane masks stay in SGPR pairs (inverse_ballot / ballot);
+// the only branch per child is the integer "cell is empty" test.
+template <bool LDS_STACK, bool STATS>
 __global__ __launch_bounds__(kBlock) void walk_fast_kernel(WalkFastArgs a)
 {
     __shared__ int32_t s_base[LDS_STACK ? kWavesPerBlock : 1][LDS_STACK ? kLdsStackDepth : 1];
@@ -67,63 +90,60 @@ __global__ __launch_bounds__(kBlock) void walk_fast_kernel(WalkFastArgs a)
     const int64_t s = a.lo + (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool valid = s < a.hi;
     const float2 p = valid ? a.spos[s] : float2{0.f, 0.f};
-    const int32_t self = valid ? (int32_t)s : -2;
     float ax = 0.f, ay = 0.f;
-    unsigned long long n_vis = 0, n_int = 0;
+    unsigned long long n_vis = 0, n_int = 0, n_wave = 0;
 
     const NodeF BH_CONSTANT *nodes = as_constant(a.nodes);
+    const float2 BH_CONSTANT *cpos = as_constant(a.spos);
+    const float BH_CONSTANT *cmass = as_constant(a.smass);
 
-    // register-lane stack
-    int32_t v_base = 0, v_lo = 0, v_hi = 0;
-    int sp = 0;
+    int32_t v_base = 0, v_lo = 0, v_hi = 0;      // register-lane stack: entry k lives in lane k
+    int sp = 0;                                   // wave-uniform
 
-    auto push = [&](int32_t base, uint64_t mask) {
-        if (LDS_STACK) {
-            if (sp < kLdsStackDepth) {
-                if (lane == 0) { s_base[w][sp] = base; s_mask[w][sp] = mask; }
-                ++sp;
-            }
-        } else {
-            if (sp < kWave) {
-                v_base = bh_writelane_i32(base, sp, v_base);
-                v_lo = bh_writelane_i32((int32_t)(uint32_t)mask, sp, v_lo);
-                v_hi = bh_writelane_i32((int32_t)(uint32_t)(mask >> 32), sp, v_hi);
-                ++sp;
-            }
-        }
-    };
-
-    auto eval = [&](const NodeF q, uint64_t mask) {
-        if (!(q.m > 1e-15f)) return;                        // empty cell, project.cu:617
-        const bool live = (mask >> lane) & 1ull;
-        if (BUCKETS && q.count > 1 && q.child < 0) {
-            // depth-cap cell holding several bodies: direct sum over its members, self excluded
-            for (int32_t j = q.first; j < q.first + q.count; ++j) {
-                const float2 o = a.spos[j];
-                const float om = a.smass[j];
-                const float dx = o.x - p.x, dy = o.y - p.y;
-                const float d2 = dx * dx + dy * dy;
-                const float ri = __builtin_amdgcn_rsqf(d2);
-                const bool ok = live && (j != self);
-                const float wgt = ok ? om * ri * ri * ri : 0.f;
-                ax = fmaf(wgt, dx, ax);
-                ay = fmaf(wgt, dy, ay);
-            }
-            if (STATS) { n_vis += __popcll(mask); n_int += (unsigned long long)__popcll(mask) * (q.count); }
-            return;
-        }
+    auto eval = [&](const NodeF q, const uint64_t mask) {
+        if (q.count == 0) return;                           // empty cell (project.cu:617)
         const float dx = q.cx - p.x, dy = q.cy - p.y;
         const float d2 = fmaf(dx, dx, dy * dy);
-        const bool far = d2 > q.thr;                        // leaves carry thr = -1
-        const bool acc = live && far && (q.occ != self);    // self skip, project.cu:646
+        // lane masks as 64-bit scalars: a v_cmp result IS its ballot, so the algebra below is SALU
+        const uint64_t farm = __ballot(d2 > q.thr);         // leaves: thr = -1; buckets: +inf
+        // d2 > 0 is the self skip (project.cu:646): a single-body leaf carries the body's own
+        // position.  It also drops an exactly coincident second body, where the reference divides
+        // by zero (inf*0 -> NaN, project.cu:651-658): fp32 positions are quantised, so that case
+        // is reachable here and one NaN would poison the root box of every later step.
+        const uint64_t accm = mask & farm & __ballot(d2 > 0.f);
+        const uint64_t open = mask & ~farm;                 // never set for leaves
         const float ri = __builtin_amdgcn_rsqf(d2);
-        const float wgt = acc ? q.m * ri * ri * ri : 0.f;
+        const float wgt = __builtin_amdgcn_inverse_ballot_w64(accm) ? q.m * ri * ri * ri : 0.f;
         ax = fmaf(wgt, dx, ax);
         ay = fmaf(wgt, dy, ay);
-        if (STATS) { n_vis += __popcll(mask); n_int += __popcll(__ballot(acc)); }
-        if (q.child >= 0) {
-            const uint64_t open = __ballot(live && !far);
-            if (open) push(q.child, open);
+        if (STATS) { n_vis += __popcll(mask); ++n_wave; n_int += __popcll(accm); }
+        if (LDS_STACK) {
+            if (lane == 0) { s_base[w][sp] = q.child; s_mask[w][sp] = open; }
+        } else {
+            v_base = bh_writelane_i32(q.child, sp, v_base);
+            v_lo = bh_writelane_i32((int32_t)(uint32_t)open, sp, v_lo);
+            v_hi = bh_writelane_i32((int32_t)(uint32_t)(open >> 32), sp, v_hi);
+        }
+        sp += (open != 0) ? 1 : 0;
+    };
+
+    // depth-cap cell holding several bodies (compat off): summed body by body for the lanes that
+    // reached it; self and exactly coincident bodies contribute nothing (d2 == 0)
+    auto bucket = [&](const NodeF q, const uint64_t mask) {
+        for (int32_t j = q.first; j < q.first + q.count; ++j) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+            const v2i ob = *(const v2i BH_CONSTANT *)(cpos + j);      // scalar loads: j is uniform
+            const float om = *(const float BH_CONSTANT *)(cmass + j);
+#pragma clang diagnostic pop
+            const float dx = __int_as_float(ob[0]) - p.x, dy = __int_as_float(ob[1]) - p.y;
+            const float d2 = fmaf(dx, dx, dy * dy);
+            const float ri = __builtin_amdgcn_rsqf(d2);
+            const uint64_t okm = mask & __ballot(d2 > 0.f);
+            const float wgt = __builtin_amdgcn_inverse_ballot_w64(okm) ? om * ri * ri * ri : 0.f;
+            ax = fmaf(wgt, dx, ax);
+            ay = fmaf(wgt, dy, ay);
+            if (STATS) n_int += __popcll(okm);
         }
     };
 
@@ -143,14 +163,17 @@ __global__ __launch_bounds__(kBlock) void walk_fast_kernel(WalkFastArgs a)
             mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v_hi, sp) << 32) |
                    (uint32_t)__builtin_amdgcn_readlane(v_lo, sp);
         }
-        const NodeF q0 = load_node(nodes + base + 0);
-        const NodeF q1 = load_node(nodes + base + 1);
-        const NodeF q2 = load_node(nodes + base + 2);
-        const NodeF q3 = load_node(nodes + base + 3);
-        eval(q0, mask);
-        eval(q1, mask);
-        eval(q2, mask);
-        eval(q3, mask);
+        if (base < 0) {                                     // bucket reference: -(node id) - 2
+            bucket(load_node(nodes + (-base - 2)), mask);
+            continue;
+        }
+        // the sibling quad is one 128-byte line: both s_load_dwordx16 are issued before any use
+        NodeF q[4];
+        load_quad(nodes + base, q);
+        eval(q[0], mask);
+        eval(q[1], mask);
+        eval(q[2], mask);
+        eval(q[3], mask);
     }
 
     if (valid) {
@@ -174,33 +197,24 @@ __global__ __launch_bounds__(kBlock) void walk_fast_kernel(WalkFastArgs a)
     if (STATS && lane == 0) {
         atomicAdd(&a.ctr->visits, n_vis);
         atomicAdd(&a.ctr->interactions, n_int);
+        atomicAdd(&a.ctr->wave_nodes, n_wave);
     }
 }
 
-template <bool L, bool S, bool B>
+template <bool L, bool S>
 static hipError_t launch(const WalkFastArgs &a, hipStream_t st)
 {
     const int64_t cnt = a.hi - a.lo;
     if (cnt <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((cnt + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL((walk_fast_kernel<L, S, B>), dim3(grid), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL((walk_fast_kernel<L, S>), dim3(grid), dim3(kBlock), 0, st, a);
     return hipGetLastError();
 }
 
-hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, bool buckets,
-                            hipStream_t st)
+hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, hipStream_t st)
 {
-    const int key = (lds_stack ? 4 : 0) | (stats ? 2 : 0) | (buckets ? 1 : 0);
-    switch (key) {
-    case 0: return launch<false, false, false>(a, st);
-    case 1: return launch<false, false, true>(a, st);
-    case 2: return launch<false, true, false>(a, st);
-    case 3: return launch<false, true, true>(a, st);
-    case 4: return launch<true, false, false>(a, st);
-    case 5: return launch<true, false, true>(a, st);
-    case 6: return launch<true, true, false>(a, st);
-    default: return launch<true, true, true>(a, st);
-    }
+    if (lds_stack) return stats ? launch<true, true>(a, st) : launch<true, false>(a, st);
+    return stats ? launch<false, true>(a, st) : launch<false, false>(a, st);
 }
 
 }  // namespace bh

@@ -57,6 +57,7 @@ class BhStats:
     steps_done: int
     visits: int
     interactions: int
+    wave_nodes: int
     last_step_ms: float
     build_ms: float
     walk_ms: float
@@ -165,7 +166,7 @@ class BarnesHutEngine:
         s = _lib.bh_stats_t()
         self._check(self._lib.bh_stats(self._h, C.byref(s)))
         return BhStats(s.n_bodies, s.n_nodes, s.n_internal, s.steps_done, s.visits, s.interactions,
-                       s.last_step_ms, s.build_ms, s.walk_ms, s.device_bytes)
+                       s.wave_nodes, s.last_step_ms, s.build_ms, s.walk_ms, s.device_bytes)
 
     # -- multi-GPU plumbing -----------------------------------------------------------------
     def set_owned_fraction(self, rank: int, world: int) -> None:

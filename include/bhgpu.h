@@ -91,6 +91,8 @@ typedef struct bh_stats_t {
     int64_t  steps_done;
     uint64_t visits;             /* BH_FLAG_WALK_STATS: body-node visits of the last walk   */
     uint64_t interactions;       /* BH_FLAG_WALK_STATS: accepted force evaluations          */
+    uint64_t wave_nodes;         /* BH_FLAG_WALK_STATS: nodes evaluated, counted once per
+                                    wavefront (= distinct nodes per 64-body group)           */
     double   last_step_ms;       /* HIP-event time of the last bh_step call / nsteps        */
     double   build_ms;           /* bounds+keys+sort+nodes+COM of the last timed step       */
     double   walk_ms;            /* walk+integrate kernel of the last timed step            */
