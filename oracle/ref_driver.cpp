@@ -95,12 +95,19 @@ int main(int argc, char** argv) {
     std::set<int> dumps;
     { std::stringstream ss(argv[4]); std::string tok; while (std::getline(ss, tok, ',')) dumps.insert(std::atoi(tok.c_str())); }
 
-    auto masses = std::make_unique<Masses>();
-    auto pos = std::make_unique<Positions>();
-    auto vel = std::make_unique<Velocities>();
-    auto acc = std::make_unique<Positions>();
-    auto frc = std::make_unique<Forces>();
-    acc->fill({0, 0}); frc->fill({0, 0});
+    // The reference's TraverseTreeToFile reads positions[occupantIdx] with occupantIdx <= -2 for
+    // single-body depth-cap cells (project.cu:515-518): an out-of-bounds read of up to N_BODIES
+    // entries BEFORE the array.  In the reference's main() the arrays are on the stack and the
+    // read lands in a neighbouring array; here they are on the heap, so a guard block of the same
+    // size sits directly in front of `pos` to keep that read inside mapped memory.
+    struct State { Positions guard; Positions pos; Velocities vel; Positions acc; Forces frc; Masses masses; };
+    auto state = std::make_unique<State>();
+    state->guard.fill({0, 0}); state->acc.fill({0, 0}); state->frc.fill({0, 0});
+    Masses* masses = &state->masses;
+    Positions* pos = &state->pos;
+    Velocities* vel = &state->vel;
+    Positions* acc = &state->acc;
+    Forces* frc = &state->frc;
 
 #if REF_KIND == 1
     loadSimulationDataFromText(dir + "/masses_init.txt", dir + "/positions_init.txt",

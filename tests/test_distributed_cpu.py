@@ -1,0 +1,87 @@
+"""World-size-2 run of the product's sharding/exchange logic (gpu_nbody_simulation_amd.distributed)
+over gloo on the CPU.  Compute comes from a stand-in engine built on the oracle (tests/ only); what
+is under test is ownership, the in-place all_gather of fixed-size blocks and the scatter back."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs(n, seed=7):
+    rng = np.random.default_rng(seed)
+    return ((10.0 ** rng.uniform(-2, 1, n)).astype(np.float32), rng.uniform(-0.1, 0.1, (n, 2)).astype(np.float32),
+            rng.uniform(-1e-4, 1e-4, (n, 2)).astype(np.float32))
+
+
+def _worker(rank, world, port, n, steps, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_standin import OracleStandInEngine
+    from gpu_nbody_simulation_amd.distributed import ShardedStepper
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, p, v = _inputs(n)
+    eng = OracleStandInEngine()
+    eng.upload(p, v, m)
+    st = ShardedStepper(eng, rank, world, n, torch.device("cpu"))
+    lo, hi = st.lo, st.hi
+    for _ in range(steps):
+        st.step()
+    pos, vel = eng.download()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=pos, vel=vel, lo=lo, hi=hi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [96, 101])          # divisible and not divisible by the world size
+def test_two_ranks_equal_one_rank(tmp_path, n):
+    world, steps = 2, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, steps, str(tmp_path)), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    # ownership: disjoint, contiguous, covering, fixed-size chunks of ceil(n/world)
+    chunk = (n + world - 1) // world
+    assert (int(r0["lo"]), int(r0["hi"])) == (0, chunk) and (int(r1["lo"]), int(r1["hi"])) == (chunk, n)
+    # replicas agree after the exchange
+    assert np.array_equal(r0["pos"], r1["pos"]) and np.array_equal(r0["vel"], r1["vel"])
+    # and equal the single-process run bit for bit (a body's walk does not depend on who runs it)
+    from dist_standin import OracleStandInEngine
+    m, p, v = _inputs(n)
+    ref = OracleStandInEngine()
+    ref.upload(p, v, m)
+    ref.set_owned_fraction(0, 1)
+    ref.step(steps)
+    pos, vel = ref.download()
+    assert np.array_equal(pos, r0["pos"]) and np.array_equal(vel, r0["vel"])
+    assert not np.array_equal(pos, p.astype(np.float64))
+
+
+def test_world_one_uses_plain_step():
+    from dist_standin import OracleStandInEngine
+    from gpu_nbody_simulation_amd.distributed import ShardedStepper
+    m, p, v = _inputs(32)
+    eng = OracleStandInEngine()
+    eng.upload(p, v, m)
+    st = ShardedStepper(eng, 0, 1, 32, torch.device("cpu"))
+    assert (st.lo, st.hi) == (0, 32)
+    st.step()
+    assert not np.array_equal(eng.download()[0], p.astype(np.float64))
