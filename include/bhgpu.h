@@ -64,9 +64,11 @@ typedef struct bh_config {
     int32_t  precision;         /* bh_precision                                             */
     int32_t  reference_compat;  /* 1: depth-cap aggregation and the `occ+2 == -i` self skip
                                    exactly as project.cu:360-382, 646 (self-interaction
-                                   artefact included).  0: a depth-cap cell holding several
-                                   bodies is still one aggregate node, but a body never
-                                   interacts with a node that contains only itself.         */
+                                   artefact included).  0: F64_EXACT keeps the aggregation but
+                                   uses main_approach_2.cpp's `occ == i` skip only (with
+                                   max_depth 32 this is the uncapped tree of ma2.cpp); F32
+                                   sums a depth-cap cell holding several bodies body by body
+                                   (bucket leaf), so no body interacts with its own cell.     */
     int32_t  device;            /* HIP device ordinal                                       */
     int32_t  n_threads;         /* N_THREADS, project.cu:5-7.  Accepted so the scaling
                                    scripts' parameter has somewhere to go; the CDNA4 launch
