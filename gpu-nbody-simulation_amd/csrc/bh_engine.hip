@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -41,6 +42,8 @@ struct bh_ctx {
     bool uploaded = false, tree_valid = false;
     int64_t internal_cap = 0, node_cap = 0;
     int sort_passes = 0;
+    bool walk_pipelined = false, walk_xcd = false;  // BH_WALK_PIPE / BH_WALK_XCD override (A/B)
+    int partial_count = 0;         // > 0: partial[] holds per-workgroup min/max of the current positions
 
     // caller-order state (double2/double or float2/float)
     void *pos = nullptr, *vel = nullptr, *mass = nullptr, *force = nullptr;
@@ -52,13 +55,15 @@ struct bh_ctx {
     uint32_t *vals[2] = {nullptr, nullptr};
     uint64_t *keys_sorted = nullptr;
     uint32_t *perm = nullptr;
-    uint32_t *radix_counts = nullptr, *bsum_u32 = nullptr, *cnt = nullptr;
+    uint32_t *radix_counts = nullptr, *bsum_sort = nullptr, *bsum_u32 = nullptr, *cnt = nullptr;
+    uint32_t *cell_first = nullptr;      // fp32: rank of a subdivided cell -> its first sorted body
     d3 *terms = nullptr, *bsum_d3 = nullptr;
     double *partial = nullptr, *box = nullptr;
     // tree
     NodeD *gd = nullptr;
     LinkD *ld = nullptr;
-    NodeF *nf = nullptr;
+    QuadF *qf = nullptr;
+    NodeAux *aux = nullptr;
     int32_t *self_node = nullptr, *cell_depth = nullptr;
     TreeCounters *ctr = nullptr;
 
@@ -119,26 +124,14 @@ void owned_range(const bh_ctx *c, int64_t *lo, int64_t *hi)
     *hi = std::min<int64_t>(c->n, chunk * (c->rank + 1));
 }
 
-// exclusive scan of `len` uint32 in place; total (if non-null) receives the sum
-int enqueue_scan_u32(bh_ctx *c, uint32_t *data, int64_t len, uint32_t *total)
+// exclusive scan of `len` uint32 in place (three launches)
+int enqueue_scan_u32(bh_ctx *c, uint32_t *data, int64_t len)
 {
     if (len <= 0) return BH_OK;
     const unsigned nb = blocks_for(len, kTile);
-    hipLaunchKernelGGL((scan_tile_sums<uint32_t>), dim3(nb), dim3(kBlock), 0, c->stream, data, c->bsum_u32, len);
-    hipLaunchKernelGGL((scan_top<uint32_t>), dim3(1), dim3(kBlock), 0, c->stream, c->bsum_u32, (int)nb, total);
-    hipLaunchKernelGGL((scan_apply<uint32_t>), dim3(nb), dim3(kBlock), 0, c->stream, data, data, c->bsum_u32, len);
-    BH_HIP(c, hipGetLastError());
-    return BH_OK;
-}
-
-int enqueue_scan_d3(bh_ctx *c, d3 *data, int64_t len)
-{
-    if (len <= 0) return BH_OK;
-    const unsigned nb = blocks_for(len, kTile);
-    hipLaunchKernelGGL((scan_tile_sums<d3>), dim3(nb), dim3(kBlock), 0, c->stream, data, c->bsum_d3, len);
-    hipLaunchKernelGGL((scan_top<d3>), dim3(1), dim3(kBlock), 0, c->stream, c->bsum_d3, (int)nb, (d3 *)nullptr);
-    hipLaunchKernelGGL((scan_apply<d3>), dim3(nb), dim3(kBlock), 0, c->stream, data, data, c->bsum_d3, len);
-    BH_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL((scan_tile_sums<uint32_t>), dim3(nb), dim3(kBlock), 0, c->stream, data, c->bsum_sort, len);
+    hipLaunchKernelGGL((scan_top<uint32_t>), dim3(1), dim3(kBlock), 0, c->stream, c->bsum_sort, (int)nb, (uint32_t *)nullptr);
+    hipLaunchKernelGGL((scan_apply<uint32_t>), dim3(nb), dim3(kBlock), 0, c->stream, data, data, c->bsum_sort, len);
     return BH_OK;
 }
 
@@ -153,69 +146,75 @@ int enqueue_build_t(bh_ctx *c)
     const Real2 *pos = static_cast<const Real2 *>(c->pos);
     const Real *mass = static_cast<const Real *>(c->mass);
 
-    // 1. root box (ComputeRootBounds, project.cu:536-573)
-    const unsigned nbb = std::max(1u, std::min(1024u, blocks_for(n, kBlock)));
-    hipLaunchKernelGGL((bounds_partial<Real2>), dim3(nbb), dim3(kBlock), 0, st, pos, n, c->partial);
-    hipLaunchKernelGGL(bounds_final, dim3(1), dim3(kBlock), 0, st, c->partial, (int)nbb, c->box);
-    BH_HIP(c, hipMemsetAsync(c->ctr, 0, sizeof(TreeCounters), st));
+    // 1. root box (ComputeRootBounds, project.cu:536-573); the per-workgroup partials usually
+    //    come from the previous step's walk epilogue
+    if (c->partial_count <= 0) {
+        const unsigned nbb = std::max(1u, std::min(1024u, blocks_for(n, kBlock)));
+        hipLaunchKernelGGL((bounds_partial<Real2>), dim3(nbb), dim3(kBlock), 0, st, pos, n, c->partial);
+        c->partial_count = (int)nbb;
+    }
+    hipLaunchKernelGGL(bounds_final, dim3(1), dim3(kBlock), 0, st, c->partial, c->partial_count, c->box, c->ctr);
+    c->partial_count = 0;
 
     if (n > 0) {
         // 2. keys by fp64 bisection, 3. stable radix sort
-        hipLaunchKernelGGL((keys_kernel<Real2>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
-                           c->box, c->keys[0], c->vals[0], n, Dm);
+        hipLaunchKernelGGL((keys_kernel<Real2>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos, c->box,
+                           c->keys[0], c->vals[0], n, Dm);
         const unsigned nbl = blocks_for(n, kTile);
         int cur = 0;
         for (int p = 0; p < c->sort_passes; ++p) {
             const int shift = p * kRadixBits;
-            hipLaunchKernelGGL((radix_hist<uint64_t>), dim3(nbl), dim3(kBlock), 0, st, c->keys[cur],
-                               c->radix_counts, n, shift, (int)nbl);
-            int rc = enqueue_scan_u32(c, c->radix_counts, (int64_t)kRadix * nbl, nullptr);
+            hipLaunchKernelGGL(radix_hist, dim3(nbl), dim3(kBlock), 0, st, c->keys[cur], c->radix_counts, n, shift,
+                               (int)nbl);
+            int rc = enqueue_scan_u32(c, c->radix_counts, (int64_t)kRadix * nbl);
             if (rc) return rc;
-            hipLaunchKernelGGL((radix_scatter<uint64_t>), dim3(nbl), dim3(kBlock), 0, st, c->keys[cur],
-                               c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1], c->radix_counts, n,
-                               shift, (int)nbl);
+            hipLaunchKernelGGL(radix_scatter, dim3(nbl), dim3(kBlock), 0, st, c->keys[cur], c->vals[cur],
+                               c->keys[cur ^ 1], c->vals[cur ^ 1], c->radix_counts, n, shift, (int)nbl);
             cur ^= 1;
         }
         c->keys_sorted = c->keys[cur];
         c->perm = c->vals[cur];
 
-        // 4. cells owned by each sorted neighbour pair, 5. their ranks
-        hipLaunchKernelGGL(pairs_kernel, dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, c->keys_sorted,
-                           c->cnt, n, Dm);
-        int rc = enqueue_scan_u32(c, c->cnt, n, &c->ctr->n_internal);
-        if (rc) return rc;
-
-        if (!EXACT) {
-            hipLaunchKernelGGL((gather_sorted_kernel<Real2, Real>), dim3(blocks_for(n + 1, kBlock)),
-                               dim3(kBlock), 0, st, c->perm, pos, mass, (Real2 *)c->spos, (Real *)c->smass,
-                               c->terms, n);
-            rc = enqueue_scan_d3(c, c->terms, n + 1);
-            if (rc) return rc;
-        }
+        // 4. cells owned by each sorted neighbour pair (+ fp32: sorted copies and prefix-sum terms),
+        // 5. their ranks / the prefix sums
+        const unsigned nbs = blocks_for(n + 1, kTile);
+        hipLaunchKernelGGL((prep_kernel<EXACT, Real2, Real>), dim3(nbs), dim3(kBlock), 0, st, c->keys_sorted,
+                           c->perm, pos, mass, c->cnt, c->bsum_u32, (Real2 *)c->spos, (Real *)c->smass, c->terms,
+                           c->bsum_d3, n, Dm);
+        hipLaunchKernelGGL(scan_top2, dim3(EXACT ? 1 : 2), dim3(kBlock), 0, st, c->bsum_u32, c->bsum_d3, (int)nbs,
+                           c->ctr);
+        hipLaunchKernelGGL((scan_apply2<EXACT>), dim3(nbs), dim3(kBlock), 0, st, c->cnt, c->bsum_u32, c->terms,
+                           c->bsum_d3, n, c->cell_first, c->internal_cap);
     } else {
         c->keys_sorted = c->keys[0];
         c->perm = c->vals[0];
     }
 
-    // 6. nodes
-    auto launch_nodes = [&](auto compat_tag) {
-        constexpr bool CP = decltype(compat_tag)::value;
-        hipLaunchKernelGGL((root_only_kernel<EXACT, CP, Real2, Real>), dim3(1), dim3(64), 0, st, pos, mass, c->perm,
-                           c->box, n, Dm, c->cfg.theta, c->gd, c->ld, c->nf, c->ctr);
-        if (n > 1)
-            hipLaunchKernelGGL((nodes_kernel<EXACT, CP, Real2, Real>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st,
-                               c->keys_sorted, c->perm, c->cnt, pos, mass, c->box, c->terms, n, Dm, c->cfg.theta,
-                               c->internal_cap, c->gd, c->ld, c->nf, c->self_node, c->cell_depth, c->ctr);
-    };
-    if (c->compat || EXACT) launch_nodes(std::true_type{}); else launch_nodes(std::false_type{});
-    if (n > 1) {
-        // 7. exact bottom-up mass pass (ComputeMass, project.cu:473-502)
-        if (EXACT) {
-            const int64_t span = std::min<int64_t>(c->internal_cap, std::max<int64_t>(1, (n - 1) * (int64_t)std::max(1, Dm)));
-            for (int d = Dm - 1; d >= 0; --d)
-                hipLaunchKernelGGL(com_level_kernel, dim3(blocks_for(span, kBlock)), dim3(kBlock), 0, st, c->gd,
-                                   c->ld, c->self_node, c->cell_depth, c->ctr, c->internal_cap, d);
-        }
+    // 6. nodes (thread 0 writes the root when nothing is subdivided)
+    const unsigned nbn = blocks_for(std::max<int64_t>(n, 1), kBlock);
+    if (EXACT) {
+        hipLaunchKernelGGL((nodes_kernel<true, true, Real2, Real>), dim3(nbn), dim3(kBlock), 0, st, c->keys_sorted,
+                           c->perm, c->cnt, pos, mass, c->box, c->terms, n, Dm, c->cfg.theta, c->internal_cap,
+                           c->gd, c->ld, c->qf, c->aux, c->self_node, c->cell_depth, c->ctr);
+    } else {
+        // one thread per subdivided cell; I <= (n-1)*Dm and <= internal_cap
+        const int64_t span = std::max<int64_t>(1, std::min<int64_t>(c->internal_cap, std::max<int64_t>(n - 1, 0) * (int64_t)std::max(1, Dm)));
+        const unsigned nbc = blocks_for(span, kBlock);
+        if (c->compat)
+            hipLaunchKernelGGL((nodes_fast_kernel<true>), dim3(nbc), dim3(kBlock), 0, st, c->keys_sorted, c->cnt,
+                               c->cell_first, c->spos, c->smass, c->box, c->terms, n, Dm, c->cfg.theta,
+                               c->internal_cap, c->qf, c->aux, c->ctr);
+        else
+            hipLaunchKernelGGL((nodes_fast_kernel<false>), dim3(nbc), dim3(kBlock), 0, st, c->keys_sorted, c->cnt,
+                               c->cell_first, c->spos, c->smass, c->box, c->terms, n, Dm, c->cfg.theta,
+                               c->internal_cap, c->qf, c->aux, c->ctr);
+    }
+    // 7. exact bottom-up mass pass (ComputeMass, project.cu:473-502)
+    if (EXACT && n > 1) {
+        const int64_t span = std::min<int64_t>(c->internal_cap, std::max<int64_t>(1, (n - 1) * (int64_t)std::max(1, Dm)));
+        for (int d = Dm - 1; d >= 0; --d)
+            hipLaunchKernelGGL(com_level_kernel, dim3(blocks_for(span, kBlock)), dim3(kBlock), 0, st, c->gd,
+                               c->ld, c->self_node, c->cell_depth, c->ctr, c->internal_cap, d);
     }
     BH_HIP(c, hipGetLastError());
     c->tree_valid = true;
@@ -230,20 +229,23 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted)
     owned_range(c, &lo, &hi);
     if (hi <= lo) return BH_OK;
     const bool stats = (c->cfg.flags & BH_FLAG_WALK_STATS) != 0;
+    // a full-range integrating walk also leaves the min/max of the NEW positions per workgroup
+    const bool want_partial = integrate && !to_sorted && lo == 0 && hi == c->n;
+    double *partial = want_partial ? c->partial : nullptr;
     if (c->exact) {
         const unsigned grid = blocks_for(hi - lo, kBlock);
         auto args = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, c->stream, c->gd, c->ld, c->perm,
                                (double2 *)c->pos, (double2 *)c->vel, (const double *)c->mass,
                                (double2 *)c->force, lo, hi, c->cfg.theta, c->cfg.G, c->cfg.dt,
-                               integrate ? 1 : 0, c->ctr);
+                               integrate ? 1 : 0, c->ctr, partial);
         };
         if (c->compat) { if (stats) args(walk_exact_kernel<true, true>); else args(walk_exact_kernel<true, false>); }
         else           { if (stats) args(walk_exact_kernel<false, true>); else args(walk_exact_kernel<false, false>); }
         BH_HIP(c, hipGetLastError());
     } else {
         WalkFastArgs a{};
-        a.nodes = c->nf; a.spos = c->spos; a.smass = c->smass; a.perm = c->perm;
+        a.quads = c->qf; a.aux = c->aux; a.partial = partial; a.spos = c->spos; a.smass = c->smass; a.perm = c->perm;
         a.pos = (float2 *)c->pos; a.vel = (float2 *)c->vel;
         a.spos_out = c->spos_out; a.svel = c->svel;
         a.acc_out = (float2 *)c->force; a.ctr = c->ctr;
@@ -251,8 +253,9 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted)
         a.integrate = integrate ? 1 : 0; a.to_sorted = to_sorted ? 1 : 0;
         // the register-lane stack holds 64 entries; the walk never needs more than 3*Dm + 2
         const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0 || (3 * c->Dm + 2 > kWave);
-        BH_HIP(c, launch_walk_fast(a, lds, stats, c->stream));
+        BH_HIP(c, launch_walk_fast(a, lds, stats, c->walk_pipelined, c->walk_xcd, c->stream));
     }
+    if (want_partial) c->partial_count = (int)blocks_for(hi - lo, kBlock);
     return BH_OK;
 }
 
@@ -300,6 +303,8 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     c->compat = cfg->reference_compat != 0;
     c->device = cfg->device;
     c->sort_passes = (2 * c->Dm + kRadixBits - 1) / kRadixBits;
+    if (const char *e = std::getenv("BH_WALK_PIPE")) c->walk_pipelined = std::atoi(e) != 0;
+    if (const char *e = std::getenv("BH_WALK_XCD")) c->walk_xcd = std::atoi(e) != 0;
     auto bail = [&](int rc) { g_create_error = c->err; bh_destroy(c); return rc; };
 
     if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(BH_ERR_DEVICE); }
@@ -327,16 +332,18 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     { char *t; A(&t, cap * 2 * rs); c->force = t; }
     A(&c->keys[0], cap); A(&c->keys[1], cap); A(&c->vals[0], cap); A(&c->vals[1], cap);
     A(&c->cnt, cap + 1);
-    const size_t nbl = blocks_for(cap, kTile);
-    A(&c->radix_counts, (size_t)kRadix * nbl);
-    A(&c->bsum_u32, std::max<size_t>(blocks_for((int64_t)kRadix * nbl, kTile), nbl) + 8);
-    A(&c->partial, 4 * 1024); A(&c->box, 4);
+    { const size_t nbl = blocks_for(cap, kTile);
+      A(&c->radix_counts, (size_t)kRadix * nbl);
+      A(&c->bsum_sort, blocks_for((int64_t)kRadix * nbl, kTile) + 8); }
+    A(&c->bsum_u32, blocks_for(cap + 1, kTile) + 8);
+    A(&c->partial, 4 * (std::max<size_t>(1024, blocks_for(cap, kBlock)) + 2)); A(&c->box, 4);
     A(&c->ctr, 1);
     if (c->exact) {
         A(&c->gd, c->node_cap); A(&c->ld, c->node_cap);
         A(&c->self_node, c->internal_cap + 1); A(&c->cell_depth, c->internal_cap + 1);
     } else {
-        A(&c->nf, c->node_cap);
+        A(&c->qf, c->internal_cap + 1); A(&c->aux, 4 * (c->internal_cap + 1));
+        A(&c->cell_first, c->internal_cap + 1);
         A(&c->spos, cap); A(&c->spos_out, cap + 1024); A(&c->svel, cap + 1024); A(&c->smass, cap);
         A(&c->terms, cap + 1); A(&c->bsum_d3, blocks_for(cap + 1, kTile) + 8);
     }
@@ -393,6 +400,7 @@ int bh_upload(bh_ctx *c, const double *pos, const double *vel, const double *mas
     }
     BH_HIP(c, hipMemset(c->force, 0, std::max<int64_t>(n, 1) * 2 * (c->exact ? sizeof(double) : sizeof(float))));
     c->n = n;
+    c->partial_count = 0;
     c->uploaded = true;
     c->tree_valid = false;
     c->steps_done = 0;
@@ -527,7 +535,8 @@ static int export_tree_host(bh_ctx *c, std::vector<bh_tree_node> &out, std::vect
     BH_HIP(c, hipMemcpy(box, c->box, sizeof(box), hipMemcpyDeviceToHost));
     std::vector<NodeD> gd;
     std::vector<LinkD> ld;
-    std::vector<NodeF> nf;
+    std::vector<QuadF> qf;
+    std::vector<NodeAux> aux;
     std::vector<uint32_t> perm(std::max<int64_t>(c->n, 1));
     if (c->n > 0) BH_HIP(c, hipMemcpy(perm.data(), c->perm, c->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (c->exact) {
@@ -535,8 +544,10 @@ static int export_tree_host(bh_ctx *c, std::vector<bh_tree_node> &out, std::vect
         BH_HIP(c, hipMemcpy(gd.data(), c->gd, nn * sizeof(NodeD), hipMemcpyDeviceToHost));
         BH_HIP(c, hipMemcpy(ld.data(), c->ld, nn * sizeof(LinkD), hipMemcpyDeviceToHost));
     } else {
-        nf.resize(nn);
-        BH_HIP(c, hipMemcpy(nf.data(), c->nf, nn * sizeof(NodeF), hipMemcpyDeviceToHost));
+        const int64_t nq = (int64_t)h.n_internal + 1;      // quad 0 = root
+        qf.resize(nq); aux.resize(4 * nq);
+        BH_HIP(c, hipMemcpy(qf.data(), c->qf, nq * sizeof(QuadF), hipMemcpyDeviceToHost));
+        BH_HIP(c, hipMemcpy(aux.data(), c->aux, 4 * nq * sizeof(NodeAux), hipMemcpyDeviceToHost));
     }
     struct Item { int32_t node; int32_t depth; int64_t parent_out; int slot; double x0, x1, y0, y1; };
     std::vector<Item> stack;
@@ -546,19 +557,22 @@ static int export_tree_host(bh_ctx *c, std::vector<bh_tree_node> &out, std::vect
     while (!stack.empty()) {
         const Item it = stack.back();
         stack.pop_back();
-        if (it.node < 0 || it.node >= nn) return fail(c, BH_ERR_DEVICE, "corrupt child link in device tree");
+        const int64_t node_limit = c->exact ? nn : 4 * ((int64_t)h.n_internal + 1);
+        if (it.node < 0 || it.node >= node_limit) return fail(c, BH_ERR_DEVICE, "corrupt child link in device tree");
         bh_tree_node q{};
-        int32_t child;
+        int32_t child;       // id of child 0, or -1
         if (c->exact) {
             q.comx = gd[it.node].cx; q.comy = gd[it.node].cy; q.mass = gd[it.node].m;
             q.particle = (double)ld[it.node].occ;
             child = ld[it.node].child;
         } else {
-            const NodeF &f = nf[it.node];
-            q.comx = f.cx; q.comy = f.cy; q.mass = f.m;
-            child = f.child;
-            if (f.child < 0 && f.count == 1) {     // single occupant: the reference's PARTICLE_INDEX
-                const int64_t body = perm[f.first];
+            const QuadF &f = qf[it.node >> 2];
+            const int sl = it.node & 3;
+            const NodeAux &ax = aux[it.node];
+            q.comx = f.xy[2 * sl]; q.comy = f.xy[2 * sl + 1]; q.mass = f.m[sl];
+            child = f.child[sl] >= 1 ? 4 * f.child[sl] : -1;
+            if (child < 0 && ax.count == 1) {      // single occupant: the reference's PARTICLE_INDEX
+                const int64_t body = perm[ax.first];
                 q.particle = (it.depth == c->Dm) ? (double)(-body - 2) : (double)body;
             } else q.particle = -1.0;
         }
@@ -734,6 +748,7 @@ int bh_scatter_sorted(bh_ctx *c)
                            c->perm, c->spos_out, c->svel, (float2 *)c->pos, (float2 *)c->vel, c->n);
         BH_HIP(c, hipGetLastError());
     }
+    c->partial_count = 0;
     c->steps_done += 1;
     return BH_OK;
 }

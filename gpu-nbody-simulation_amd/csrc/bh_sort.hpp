@@ -1,0 +1,144 @@
+// bh_sort.hpp -- stable LSD radix sort of (key, body) pairs for the tree build, and the generic
+// three-kernel exclusive scan it uses.  Included by the engine translation unit only.
+//
+//   radix_hist    : counts[digit * nblocks + block] = occurrences of digit in tile `block`
+//   scan (3 launches) of counts in digit-major order => global base of every (digit, block)
+//   radix_scatter : stable scatter of the tile using per-round ballot matching
+// A round handles 256 consecutive elements (thread t <-> element round*256 + t), so ranks follow
+// element order and equal keys keep their input order.
+//
+// (Measured alternative, rejected: letting every scatter workgroup derive its own offsets from the
+// count matrix saves three launches per pass but re-reads the 256 x nblocks matrix per workgroup;
+// at N = 1M it took 37 us per pass against 18 us + 14 us for scatter + scan.)
+#pragma once
+
+#include "bh_prims.hpp"
+
+namespace bh {
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scan_tile_sums(const T *__restrict__ in, T *__restrict__ bsum,
+                                                          int64_t n)
+{
+    __shared__ T sm[kWavesPerBlock + 1];
+    const int64_t base = (int64_t)blockIdx.x * kTile;
+    T s = zero_of<T>();
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {                      // striped: coalesced, order irrelevant
+        const int64_t i = base + k * kBlock + threadIdx.x;
+        if (i < n) s += in[i];
+    }
+    T tot;
+    (void)block_exclusive_sum(s, sm, tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scan_top(T *__restrict__ bsum, int nb, T *__restrict__ total)
+{
+    __shared__ T sm[kWavesPerBlock + 1];
+    T carry = zero_of<T>();
+    for (int c0 = 0; c0 < nb; c0 += kBlock) {
+        const int i = c0 + threadIdx.x;
+        T v = (i < nb) ? bsum[i] : zero_of<T>();
+        T tot;
+        T ex = block_exclusive_sum(v, sm, tot);
+        if (i < nb) bsum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total) *total = carry;
+}
+
+// in == out allowed.  Row by row (256 consecutive elements per block scan): coalesced accesses.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scan_apply(const T *in, T *out, const T *__restrict__ bsum,
+                                                      int64_t n)
+{
+    __shared__ T sm[kWavesPerBlock + 1];
+    const int64_t base = (int64_t)blockIdx.x * kTile;
+    T carry = bsum[blockIdx.x];
+#pragma unroll 1
+    for (int k = 0; k < kItems; ++k) {
+        const int64_t i = base + k * kBlock + threadIdx.x;
+        const T v = (i < n) ? in[i] : zero_of<T>();
+        T tot;
+        const T ex = block_exclusive_sum(v, sm, tot);
+        if (i < n) out[i] = carry + ex;
+        carry += tot;
+    }
+}
+
+constexpr int kRadixBits = 8;
+constexpr int kRadix = 1 << kRadixBits;
+static_assert(kRadix == kBlock, "one thread per digit");
+
+__global__ __launch_bounds__(kBlock) void radix_hist(const uint64_t *__restrict__ keys,
+                                                      uint32_t *__restrict__ counts, int64_t n,
+                                                      int shift, int nblocks)
+{
+    __shared__ uint32_t h[kRadix];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kTile;
+#pragma unroll
+    for (int r = 0; r < kItems; ++r) {
+        const int64_t i = base + r * kBlock + threadIdx.x;
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (kRadix - 1)], 1u);
+    }
+    __syncthreads();
+    counts[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kBlock) void radix_scatter(const uint64_t *__restrict__ kin,
+                                                         const uint32_t *__restrict__ vin,
+                                                         uint64_t *__restrict__ kout,
+                                                         uint32_t *__restrict__ vout,
+                                                         const uint32_t *__restrict__ offs, int64_t n,
+                                                         int shift, int nblocks)
+{
+    __shared__ uint32_t run[kRadix];
+    __shared__ uint32_t wcnt[kWavesPerBlock][kRadix];
+    __shared__ uint32_t gbase[kRadix];
+    const int t = threadIdx.x, w = wave_id(), l = lane_id();
+    gbase[t] = offs[(int64_t)t * nblocks + blockIdx.x];
+    run[t] = 0;
+#pragma unroll
+    for (int k = 0; k < kWavesPerBlock; ++k) wcnt[k][t] = 0;
+    __syncthreads();
+
+    const int64_t base = (int64_t)blockIdx.x * kTile;
+    const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
+#pragma unroll 1
+    for (int r = 0; r < kItems; ++r) {
+        const int64_t i = base + r * kBlock + t;
+        const bool valid = i < n;
+        const uint64_t key = valid ? kin[i] : 0ull;
+        const uint32_t val = valid ? vin[i] : 0u;
+        const uint32_t d = (uint32_t)(key >> shift) & (kRadix - 1);
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < kRadixBits; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const uint32_t rank = __popcll(peers & lt);
+        if (valid && rank == 0) wcnt[w][d] = __popcll(peers);
+        __syncthreads();
+        if (valid) {
+            uint32_t o = run[d] + rank;
+            for (int k = 0; k < w; ++k) o += wcnt[k][d];
+            const int64_t dst = (int64_t)gbase[d] + o;
+            kout[dst] = key;
+            vout[dst] = val;
+        }
+        __syncthreads();
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < kWavesPerBlock; ++k) { s += wcnt[k][t]; wcnt[k][t] = 0; }
+        run[t] += s;
+        __syncthreads();
+    }
+}
+
+}  // namespace bh

@@ -7,7 +7,8 @@
 // (project.cu:349-355, 417-418).  So the same tree can be derived from sorted Morton-style keys
 // whose digits are produced by the SAME fp64 bisection:
 //
-//   keys      : per body, max_depth-1 bisection steps -> 2 bits per level (child index 0..3)
+//   keys      : per body, max_depth-1 bisection steps -> 2 bits per level (child index 0..3);
+//               the same kernel histograms the first radix digit
 //   sort      : stable radix sort of (key, body) -> bodies of one cell are contiguous and, inside
 //               a depth-cap cell, stay in body order (the order the reference's running
 //               centre-of-mass fold uses, project.cu:371-373)
@@ -20,13 +21,20 @@
 //   com       : exact mode: bottom-up, level by level, children summed in index order exactly as
 //               ComputeMass does (project.cu:473-502).  fp32 mode: from fp64 prefix sums.
 //
+// Launch count matters as much as kernel quality here: on MI355X every launch costs ~6 us (4.7 us
+// minimum kernel duration + boundary), so the pipeline is fused to 16 launches per step at
+// max_depth 21 (it was 40): bounds_final | keys+hist | 5 x (scatter, hist) | prep | scan_top2 |
+// scan_apply2 | nodes | walk.
+//
 // Depth convention: d = 0 is the root ("file depth", TraverseTreeToFile's first column);
 // Dm = max_depth-1 is the depth of the cap cells.  Everything here is compiled with
 // -ffp-contract=off.
 #pragma once
 
 #include "bh_prims.hpp"
+#include "bh_sort.hpp"
 #include "bh_nodes.hpp"
+#include "bh_bounds.hpp"
 
 namespace bh {
 
@@ -62,8 +70,9 @@ __global__ __launch_bounds__(kBlock) void bounds_partial(const Real2 *__restrict
     }
 }
 
+// final reduction + the padding of project.cu:553-570; also clears the per-step counters
 __global__ __launch_bounds__(kBlock) void bounds_final(const double *__restrict__ partial, int nb,
-                                                        double *__restrict__ box)
+                                                        double *__restrict__ box, TreeCounters *ctr)
 {
     __shared__ double sm[4][kWavesPerBlock];
     double xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
@@ -85,6 +94,8 @@ __global__ __launch_bounds__(kBlock) void bounds_final(const double *__restrict_
         double pad = 0.1 * span;
         if (span == 0.0) pad = 1e-6;
         box[0] = xlo - pad; box[1] = xhi + pad; box[2] = ylo - pad; box[3] = yhi + pad;
+        ctr->n_internal = 0; ctr->overflow = 0;
+        ctr->visits = 0; ctr->interactions = 0; ctr->wave_nodes = 0;
     }
 }
 
@@ -125,21 +136,134 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
     idx[i] = (uint32_t)i;
 }
 
-// ---- pairs: how many subdivided cells does sorted body i start? --------------------------------
-__global__ __launch_bounds__(kBlock) void pairs_kernel(const uint64_t *__restrict__ keys,
-                                                        uint32_t *__restrict__ cnt, int64_t n, int Dm)
+// ---- after the sort: cell counts per sorted body (+ fp32: sorted copies and prefix-sum terms) ----
+// One workgroup per scan tile (kTile consecutive sorted bodies); element k*256 + t belongs to
+// thread t, so every access is coalesced.  Also produces the tile sums of both scans, so no
+// separate reduction launches are needed.
+template <bool EXACT, typename Real2, typename Real>
+__global__ __launch_bounds__(kBlock) void prep_kernel(const uint64_t *__restrict__ keys,
+                                                       const uint32_t *__restrict__ perm,
+                                                       const Real2 *__restrict__ pos,
+                                                       const Real *__restrict__ mass,
+                                                       uint32_t *__restrict__ cnt,
+                                                       uint32_t *__restrict__ bsum_u32,
+                                                       Real2 *__restrict__ spos, Real *__restrict__ smass,
+                                                       d3 *__restrict__ terms, d3 *__restrict__ bsum_d3,
+                                                       int64_t n, int Dm)
 {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    uint32_t c = 0;
-    if (i + 1 < n) {
-        const uint64_t k = keys[i];
-        const int L = shared_levels(k, keys[i + 1], Dm);
-        const int Lp = (i == 0) ? -1 : shared_levels(keys[i - 1], k, Dm);
-        const int hi = (L < Dm - 1) ? L : Dm - 1;
-        c = (hi > Lp) ? (uint32_t)(hi - Lp) : 0u;
+    __shared__ uint32_t smu[kWavesPerBlock + 1];
+    __shared__ d3 smd[kWavesPerBlock + 1];
+    const int64_t base = (int64_t)blockIdx.x * kTile;
+    uint32_t csum = 0;
+    d3 tsum{0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const int64_t i = base + k * kBlock + threadIdx.x;
+        if (i < n) {
+            uint32_t c = 0;
+            if (i + 1 < n) {
+                const uint64_t kc = keys[i];
+                const int L = shared_levels(kc, keys[i + 1], Dm);
+                const int Lp = (i == 0) ? -1 : shared_levels(keys[i - 1], kc, Dm);
+                const int hi = (L < Dm - 1) ? L : Dm - 1;
+                c = (hi > Lp) ? (uint32_t)(hi - Lp) : 0u;
+            }
+            cnt[i] = c;
+            csum += c;
+            if (!EXACT) {
+                const uint32_t b = perm[i];
+                const Real2 p = pos[b];
+                const Real m = mass[b];
+                spos[i] = p;
+                smass[i] = m;
+                const d3 t{(double)m, (double)m * (double)p.x, (double)m * (double)p.y};
+                terms[i] = t;
+                tsum += t;
+            }
+        } else if (!EXACT && i == n) {
+            terms[n] = d3{0.0, 0.0, 0.0};
+        }
     }
-    cnt[i] = c;
+    uint32_t utot;
+    (void)block_exclusive_sum(csum, smu, utot);
+    if (threadIdx.x == 0) bsum_u32[blockIdx.x] = utot;
+    if (!EXACT) {
+        d3 dtot;
+        (void)block_exclusive_sum(tsum, smd, dtot);
+        if (threadIdx.x == 0) bsum_d3[blockIdx.x] = dtot;
+    }
+}
+
+// block 0: exclusive scan of the u32 tile sums (total -> n_internal); block 1: the d3 tile sums
+__global__ __launch_bounds__(kBlock) void scan_top2(uint32_t *__restrict__ bsum_u32,
+                                                     d3 *__restrict__ bsum_d3, int nb,
+                                                     TreeCounters *ctr)
+{
+    if (blockIdx.x == 0) {
+        __shared__ uint32_t sm[kWavesPerBlock + 1];
+        uint32_t carry = 0;
+        for (int c0 = 0; c0 < nb; c0 += kBlock) {
+            const int i = c0 + threadIdx.x;
+            const uint32_t v = (i < nb) ? bsum_u32[i] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_exclusive_sum(v, sm, tot);
+            if (i < nb) bsum_u32[i] = carry + ex;
+            carry += tot;
+        }
+        if (threadIdx.x == 0) ctr->n_internal = carry;
+    } else {
+        __shared__ d3 sm[kWavesPerBlock + 1];
+        d3 carry{0.0, 0.0, 0.0};
+        for (int c0 = 0; c0 < nb; c0 += kBlock) {
+            const int i = c0 + threadIdx.x;
+            const d3 v = (i < nb) ? bsum_d3[i] : d3{0.0, 0.0, 0.0};
+            d3 tot;
+            const d3 ex = block_exclusive_sum(v, sm, tot);
+            if (i < nb) bsum_d3[i] = carry + ex;
+            carry += tot;
+        }
+    }
+}
+
+// per tile: cnt -> exclusive offsets (ranks), fp32: terms -> exclusive prefix sums (n+1 entries);
+// row by row (256 consecutive elements per block scan), so accesses are coalesced
+template <bool EXACT>
+__global__ __launch_bounds__(kBlock) void scan_apply2(uint32_t *__restrict__ cnt,
+                                                       const uint32_t *__restrict__ bsum_u32,
+                                                       d3 *__restrict__ terms,
+                                                       const d3 *__restrict__ bsum_d3, int64_t n,
+                                                       uint32_t *__restrict__ cell_first,
+                                                       int64_t internal_cap)
+{
+    __shared__ uint32_t smu[kWavesPerBlock + 1];
+    __shared__ d3 smd[kWavesPerBlock + 1];
+    const int64_t base = (int64_t)blockIdx.x * kTile;
+    uint32_t ucarry = bsum_u32[blockIdx.x];
+    d3 dcarry = EXACT ? d3{0.0, 0.0, 0.0} : bsum_d3[blockIdx.x];
+#pragma unroll 1
+    for (int k = 0; k < kItems; ++k) {
+        const int64_t i = base + k * kBlock + threadIdx.x;
+        const uint32_t v = (i < n) ? cnt[i] : 0u;
+        uint32_t utot;
+        const uint32_t uex = block_exclusive_sum(v, smu, utot);
+        if (i < n) {
+            const uint32_t r0 = ucarry + uex;
+            cnt[i] = r0;
+            // rank -> first body of the cell: lets the node kernel run one thread per CELL (the
+            // body that starts a whole chain of nested cells would otherwise process them serially)
+            if (!EXACT)
+                for (uint32_t k = 0; k < v; ++k)
+                    if ((int64_t)(r0 + k) < internal_cap) cell_first[r0 + k] = (uint32_t)i;
+        }
+        ucarry += utot;
+        if (!EXACT) {
+            const d3 t = (i <= n) ? terms[i] : d3{0.0, 0.0, 0.0};
+            d3 dtot;
+            const d3 dex = block_exclusive_sum(t, smd, dtot);
+            if (i <= n) terms[i] = dcarry + dex;
+            dcarry += dtot;
+        }
+    }
 }
 
 // first index j in [lo, hi) with (keys[j] >> sh) >= target   (keys sorted)
@@ -153,57 +277,76 @@ __device__ __forceinline__ int64_t lower_bound_prefix(const uint64_t *__restrict
     return lo;
 }
 
-// ---- root record when nothing is subdivided (n <= 1, or max_depth == 1) ------------------------
-template <bool EXACT, bool COMPAT, typename Real2, typename Real>
-__global__ void root_only_kernel(const Real2 *__restrict__ pos, const Real *__restrict__ mass,
-                                 const uint32_t *__restrict__ perm, const double *__restrict__ box,
-                                 int64_t n, int Dm, double theta, NodeD *gd, LinkD *ld, NodeF *nf,
-                                 const TreeCounters *ctr)
+// End of the cell with depth-d prefix `pfx` that starts at body i: first j in (i, hi] outside it.
+// keys[i+1] is known to be inside.  Galloping then bisection: O(log(cell size)) loads, not
+// O(log N) -- most cells hold a handful of bodies.
+__device__ __forceinline__ int64_t cell_end(const uint64_t *__restrict__ keys, int64_t i, int64_t hi,
+                                            int sh, uint64_t pfx)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (ctr->n_internal != 0) return;
-    double m = 0.0, cx = 0.0, cy = 0.0;
-    int occ = -1;
-    if (n >= 1 && Dm == 0) {              // root itself is a depth-cap cell, project.cu:360-382
-        for (int64_t j = 0; j < n; ++j) {
-            const uint32_t b = perm[j];
-            const double bm = (double)mass[b], bx = (double)pos[b].x, by = (double)pos[b].y;
-            cx = (m * cx + bm * bx) / (m + bm);
-            cy = (m * cy + bm * by) / (m + bm);
-            m += bm;
-        }
-        occ = (n == 1) ? (EXACT ? -(int)perm[0] - 2 : 0) : -1;
-    } else if (n == 1) {                  // empty root takes the body, project.cu:398-406
-        const uint32_t b = perm[0];
-        m = (double)mass[b]; cx = (double)pos[b].x; cy = (double)pos[b].y;
-        occ = EXACT ? (int)b : 0;
+    int64_t a = i + 1, step = 1, b;
+    for (;;) {
+        b = a + step;
+        if (b >= hi) { b = hi; break; }
+        if ((keys[b] >> sh) != pfx) break;
+        a = b;
+        step <<= 1;
     }
-    const double ex = box[1] - box[0], ey = box[3] - box[2];
-    const double size = (ex > ey) ? ex : ey;
-    if (EXACT) {
-        gd[0] = NodeD{cx, cy, m, size};
-        ld[0] = LinkD{-1, occ};
-    } else {
-        NodeF r;
-        r.cx = (float)cx; r.cy = (float)cy; r.m = (float)m; r.thr = -1.0f;
-        r.child = -1; r.first = 0; r.count = (m > 1e-15) ? (int32_t)n : 0; r.pad = 0;
-        if (n > 1 && !COMPAT) { r.child = -2; r.thr = INFINITY; }     // root itself is a bucket
-        nf[0] = r;
-    }
+    return lower_bound_prefix(keys, a + 1, b, sh, pfx + 1);
 }
 
 // ---- nodes: the owner of each subdivided cell writes its four children --------------------------
 // EXACT: NodeD/LinkD + self_node/cell_depth for the bottom-up pass.
-// !EXACT: NodeF complete (COM from the fp64 prefix sums psum[0..n], psum[j] = sum over sorted < j).
+// !EXACT: one QuadF per cell, complete (COM from the fp64 prefix sums psum[0..n]) + NodeAux.
+// Thread 0 also writes the root when nothing is subdivided (n <= 1 or max_depth == 1).
 template <bool EXACT, bool COMPAT, typename Real2, typename Real>
 __global__ __launch_bounds__(kBlock) void nodes_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm,
     const uint32_t *__restrict__ off, const Real2 *__restrict__ pos, const Real *__restrict__ mass,
     const double *__restrict__ box, const d3 *__restrict__ psum, int64_t n, int Dm, double theta,
-    int64_t internal_cap, NodeD *__restrict__ gd, LinkD *__restrict__ ld, NodeF *__restrict__ nf,
-    int32_t *__restrict__ self_node, int32_t *__restrict__ cell_depth, TreeCounters *ctr)
+    int64_t internal_cap, NodeD *__restrict__ gd, LinkD *__restrict__ ld, QuadF *__restrict__ qf,
+    NodeAux *__restrict__ aux, int32_t *__restrict__ self_node, int32_t *__restrict__ cell_depth,
+    TreeCounters *ctr)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t total = ctr->n_internal;
+
+    if (i == 0 && total == 0) {
+        // ---- root only: empty root takes the body (project.cu:398-406) or the root itself is a
+        //      depth-cap cell (max_depth == 1, project.cu:360-382)
+        double m = 0.0, cx = 0.0, cy = 0.0;
+        int occ = -1;
+        if (n >= 1 && Dm == 0) {
+            for (int64_t j = 0; j < n; ++j) {
+                const uint32_t b = perm[j];
+                const double bm = (double)mass[b], bx = (double)pos[b].x, by = (double)pos[b].y;
+                cx = (m * cx + bm * bx) / (m + bm);
+                cy = (m * cy + bm * by) / (m + bm);
+                m += bm;
+            }
+            occ = (n == 1) ? -(int)perm[0] - 2 : -1;
+        } else if (n == 1) {
+            const uint32_t b = perm[0];
+            m = (double)mass[b]; cx = (double)pos[b].x; cy = (double)pos[b].y;
+            occ = (int)b;
+        }
+        const double ex = box[1] - box[0], ey = box[3] - box[2];
+        const double size = (ex > ey) ? ex : ey;
+        if (EXACT) {
+            gd[0] = NodeD{cx, cy, m, size};
+            ld[0] = LinkD{-1, occ};
+        } else {
+            QuadF q;
+            for (int k = 0; k < 4; ++k) { q.xy[2 * k] = 0.f; q.xy[2 * k + 1] = 0.f; q.m[k] = 0.f; q.thr[k] = 0.f; q.child[k] = -1; }
+            q.xy[0] = (float)cx; q.xy[1] = (float)cy;
+            q.m[0] = (m > 1e-15) ? (float)m : 0.f;
+            if (n > 1 && !COMPAT) { q.child[0] = -2; q.thr[0] = INFINITY; }   // root itself is a bucket
+            qf[0] = q;
+            aux[0] = NodeAux{0, (int32_t)n};
+            for (int k = 1; k < 4; ++k) aux[k] = NodeAux{0, 0};
+        }
+        return;
+    }
+
     if (i + 1 >= n) return;
     const uint64_t key = keys[i];
     const int L = shared_levels(key, keys[i + 1], Dm);
@@ -211,7 +354,6 @@ __global__ __launch_bounds__(kBlock) void nodes_kernel(
     const int dlo = Lp + 1;
     const int dhi = (L < Dm - 1) ? L : Dm - 1;
     if (dhi < dlo) return;
-    const uint32_t total = ctr->n_internal;
     if ((int64_t)total > internal_cap) {
         if (i == 0) ctr->overflow = 1;
         return;
@@ -230,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void nodes_kernel(
         const uint32_t r = r0 + (uint32_t)(d - dlo);
         const int sh = 2 * (Dm - d);                 // bits below the depth-d prefix
         const uint64_t pfx = (d == 0) ? 0ull : (key >> sh);
-        const int64_t e = (d == 0) ? n : lower_bound_prefix(keys, i + 1, hi, sh, pfx + 1);
+        const int64_t e = (d == 0) ? n : cell_end(keys, i, hi, sh, pfx);
         hi = e;
         const int shc = sh - 2;
         int64_t b[5];
@@ -238,9 +380,9 @@ __global__ __launch_bounds__(kBlock) void nodes_kernel(
         for (int c = 1; c < 4; ++c) b[c] = lower_bound_prefix(keys, b[c - 1], e, shc, (pfx << 2) | (uint64_t)c);
 
         const double mx = (x0 + x1) / 2.0, my = (y0 + y1) / 2.0;
-        const int32_t quad = 1 + 4 * (int32_t)r;
+        const int32_t quad = EXACT ? 1 + 4 * (int32_t)r : 4 * ((int32_t)r + 1);   // id of child 0
 
-        if (d == 0) {                                  // root record (static part)
+        if (d == 0) {                                  // root record
             const double ex = x1 - x0, ey = y1 - y0;
             const double size = (ex > ey) ? ex : ey;
             if (EXACT) {
@@ -249,17 +391,22 @@ __global__ __launch_bounds__(kBlock) void nodes_kernel(
                 self_node[0] = 0;
                 cell_depth[0] = 0;
             } else {
-                NodeF rt;
+                QuadF q;
+                for (int k = 0; k < 4; ++k) { q.xy[2 * k] = 0.f; q.xy[2 * k + 1] = 0.f; q.m[k] = 0.f; q.thr[k] = 0.f; q.child[k] = -1; }
                 const d3 t = psum[n];
-                rt.m = (float)t.a; rt.cx = (float)(t.b / t.a); rt.cy = (float)(t.c / t.a);
-                const double q = size * inv_theta;
-                rt.thr = (float)(q * q);
-                rt.child = quad; rt.first = 0; rt.count = (int32_t)n; rt.pad = 0;
-                if (!(t.a > 1e-15)) { rt.child = -1; rt.count = 0; }
-                nf[0] = rt;
+                if (t.a > 1e-15) {
+                    q.m[0] = (float)t.a; q.xy[0] = (float)(t.b / t.a); q.xy[1] = (float)(t.c / t.a);
+                    const double s = size * inv_theta;
+                    q.thr[0] = (float)(s * s);
+                    q.child[0] = (int32_t)r + 1;
+                }
+                qf[0] = q;
+                aux[0] = NodeAux{0, (int32_t)n};
+                for (int k = 1; k < 4; ++k) aux[k] = NodeAux{0, 0};
             }
         }
 
+        QuadF q;
         for (int c = 0; c < 4; ++c) {
             const double cx0 = (c & 1) ? mx : x0, cx1 = (c & 1) ? x1 : mx;
             const double cy0 = (c & 2) ? my : y0, cy1 = (c & 2) ? y1 : my;
@@ -269,12 +416,12 @@ __global__ __launch_bounds__(kBlock) void nodes_kernel(
             const int32_t node = quad + c;
             double m = 0.0, cx = 0.0, cy = 0.0;
             int32_t child = -1, occ = -1;
-            bool internal = false, bucket = false;
+            float thr = -1.0f;
             if (nc == 0) {
                 // empty leaf: blank child of project.cu:422-428
             } else if (d + 1 == Dm) {
-                // depth-cap cell, project.cu:360-382: running mean in body order
-                if (EXACT) {
+                // depth-cap cell, project.cu:360-382
+                if (EXACT) {                           // running mean in body order
                     for (int64_t j = bc; j < bc + nc; ++j) {
                         const uint32_t bi = perm[j];
                         const double bm = (double)mass[bi], bx = (double)pos[bi].x, by = (double)pos[bi].y;
@@ -283,53 +430,199 @@ __global__ __launch_bounds__(kBlock) void nodes_kernel(
                         m += bm;
                     }
                     occ = (nc == 1) ? (-(int32_t)perm[bc] - 2) : -1;
+                } else if (nc == 1) {
+                    const uint32_t bi = perm[bc];
+                    cx = (double)pos[bi].x; cy = (double)pos[bi].y; m = (double)mass[bi];
                 } else {
                     const d3 lo_s = psum[bc], hi_s = psum[bc + nc];
                     m = hi_s.a - lo_s.a;
-                    if (nc == 1) { const uint32_t bi = perm[bc]; cx = (double)pos[bi].x; cy = (double)pos[bi].y; m = (double)mass[bi]; }
-                    else { cx = (hi_s.b - lo_s.b) / m; cy = (hi_s.c - lo_s.c) / m; }
-                    occ = (nc == 1) ? (int32_t)bc : -1;
-                    bucket = (nc > 1) && !COMPAT;
+                    cx = (hi_s.b - lo_s.b) / m; cy = (hi_s.c - lo_s.c) / m;
+                    if (!COMPAT) { thr = INFINITY; child = -node - 2; }    // bucket leaf
                 }
             } else if (nc == 1) {
                 // single body in an undivided cell, project.cu:398-406
                 const uint32_t bi = perm[bc];
                 m = (double)mass[bi]; cx = (double)pos[bi].x; cy = (double)pos[bi].y;
-                occ = EXACT ? (int32_t)bi : (int32_t)bc;
+                occ = (int32_t)bi;
             } else {
                 // subdivided cell: its rank follows from its first body and depth
-                internal = true;
                 const int Lpc = (bc == 0) ? -1 : shared_levels(keys[bc - 1], keys[bc], Dm);
                 const uint32_t rc = off[bc] + (uint32_t)((d + 1) - (Lpc + 1));
-                child = 1 + 4 * (int32_t)rc;
                 if (EXACT) {
+                    child = 1 + 4 * (int32_t)rc;
                     self_node[rc] = node;
                     cell_depth[rc] = d + 1;
                 } else {
+                    child = (int32_t)rc + 1;
                     const d3 lo_s = psum[bc], hi_s = psum[bc + nc];
                     m = hi_s.a - lo_s.a;
                     cx = (hi_s.b - lo_s.b) / m; cy = (hi_s.c - lo_s.c) / m;
+                    const double s = size * inv_theta;
+                    thr = (float)(s * s);
                 }
             }
             if (EXACT) {
                 gd[node] = NodeD{cx, cy, m, size};
                 ld[node] = LinkD{child, occ};
             } else {
-                NodeF q;
-                q.cx = (float)cx; q.cy = (float)cy; q.m = (float)m;
-                if (internal) { const double s = size * inv_theta; q.thr = (float)(s * s); }
-                else if (bucket) { q.thr = INFINITY; child = -node - 2; }
-                else q.thr = -1.0f;
-                q.child = child; q.first = (int32_t)bc; q.count = (int32_t)nc; q.pad = 0;
-                if (nc > 0 && !(m > 1e-15)) { q.child = -1; q.count = 0; q.thr = -1.0f; }
-                nf[node] = q;
+                if (!(m > 1e-15)) { m = 0.0; cx = 0.0; cy = 0.0; child = -1; thr = -1.0f; }   // project.cu:617
+                q.xy[2 * c] = (float)cx; q.xy[2 * c + 1] = (float)cy; q.m[c] = (float)m; q.thr[c] = thr; q.child[c] = child;
+                aux[node] = NodeAux{(int32_t)bc, (int32_t)nc};
             }
         }
+        if (!EXACT) qf[r + 1] = q;
         // descend into the child that holds body i (the next cell of this owner's chain)
         if (d < dhi) {
             const int c = (int)((key >> (2 * (Dm - 1 - d))) & 3);
             descend(c, mx, my, x0, x1, y0, y1);
         }
+    }
+}
+
+// ---- fp32 nodes kernel ------------------------------------------------------------------------------
+// Same ownership scheme as nodes_kernel, specialised for the throughput path:
+//   * a window of the sorted keys (the workgroup's 256 bodies, one predecessor and a 768-key halo)
+//     is cached in LDS: the range searches of almost every cell stay inside it (a cell with more
+//     than ~800 bodies falls back to global loads -- there are only a few thousand such cells);
+//   * no fp64 box tracking: fp32 only needs the MAC threshold (size/theta)^2, and the cell size at
+//     depth d is root_size * 2^-d to far better than fp32 resolution;
+//   * single bodies come from the sorted copies (neighbouring addresses), not through perm;
+//   * fields are stored as they are produced, so the kernel stays under 64 VGPRs (8 waves/SIMD;
+//     the generic kernel needs 104 and ran at 4).
+constexpr int kKeyHalo = 768;
+constexpr int kKeyWin = kBlock + 1 + kKeyHalo;
+
+template <bool COMPAT>
+__global__ __launch_bounds__(kBlock, 8) void nodes_fast_kernel(
+    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ off,
+    const uint32_t *__restrict__ cell_first, const float2 *__restrict__ spos,
+    const float *__restrict__ smass, const double *__restrict__ box, const d3 *__restrict__ psum,
+    int64_t n64, int Dm, double theta, int64_t internal_cap, QuadF *__restrict__ qf,
+    NodeAux *__restrict__ aux, TreeCounters *ctr)
+{
+    // ONE THREAD PER SUBDIVIDED CELL (rank r): its first body comes from cell_first[r], its depth
+    // from its position in that body's chain.  32-bit indices throughout (bh_create caps n < 2^31).
+    __shared__ uint64_t wkeys[kKeyWin];
+    __shared__ int32_t s_wlo;
+    const int32_t n = (int32_t)n64;
+    const uint32_t total = ctr->n_internal;
+    float *qw = reinterpret_cast<float *>(qf);                  // 20 dwords per quad
+    int32_t *qi = reinterpret_cast<int32_t *>(qf);
+    auto put = [&](int32_t quad, int slot, float cx, float cy, float m, float thr, int32_t child) {
+        const int64_t o = (int64_t)quad * 20;
+        qw[o + 2 * slot] = cx; qw[o + 2 * slot + 1] = cy; qw[o + 8 + slot] = m; qw[o + 12 + slot] = thr;
+        qi[o + 16 + slot] = child;
+    };
+
+    if (total == 0) {
+        // root only (n <= 1, or max_depth == 1)
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            for (int k = 0; k < 4; ++k) { put(0, k, 0.f, 0.f, 0.f, -1.f, -1); aux[k] = NodeAux{0, 0}; }
+            if (n >= 1) {
+                const d3 t = psum[n];
+                const bool one = (n == 1);
+                const float cx = one ? spos[0].x : (float)(t.b / t.a), cy = one ? spos[0].y : (float)(t.c / t.a);
+                const float m = (t.a > 1e-15) ? (one ? smass[0] : (float)t.a) : 0.f;
+                const bool bucket = (n > 1) && !COMPAT;
+                put(0, 0, cx, cy, m, bucket ? INFINITY : 0.f, bucket ? -2 : -1);
+                aux[0] = NodeAux{0, (int32_t)n};
+            }
+        }
+        return;
+    }
+    if ((int64_t)total > internal_cap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctr->overflow = 1;
+        return;
+    }
+    const uint32_t r_block = blockIdx.x * kBlock;
+    if (r_block >= total) return;                               // uniform per workgroup
+
+    // key window starting one body before the first cell of this workgroup
+    if (threadIdx.x == 0) s_wlo = (int32_t)cell_first[r_block] - 1;
+    __syncthreads();
+    const int32_t wlo = s_wlo;
+    for (int k = threadIdx.x; k < kKeyWin; k += kBlock) {
+        const int32_t j = wlo + k;
+        wkeys[k] = (j >= 0 && j < n) ? keys[j] : 0ull;
+    }
+    __syncthreads();
+    auto K = [&](int32_t j) -> uint64_t {
+        const int32_t k = j - wlo;
+        return (k >= 0 && k < kKeyWin) ? wkeys[k] : keys[j];
+    };
+
+    const uint32_t r = r_block + threadIdx.x;
+    if (r >= total) return;
+    const int32_t i = (int32_t)cell_first[r];
+    const uint64_t key = K(i);
+    const int Lp = (i == 0) ? -1 : shared_levels(K(i - 1), key, Dm);
+    const int d = Lp + 1 + (int)(r - off[i]);                   // this cell's depth
+
+    const double ex0 = box[1] - box[0], ey0 = box[3] - box[2];
+    const double q0 = ((ex0 > ey0) ? ex0 : ey0) / theta;       // size/theta at depth 0
+    const double thr0 = q0 * q0;
+
+    const int sh = 2 * (Dm - d);
+    const uint64_t pfx = (d == 0) ? 0ull : (key >> sh);
+    int32_t e;
+    if (d == 0) e = n;
+    else {                                                       // galloping, then bisection
+        int32_t a = i + 1, step = 1, b;
+        for (;;) {
+            b = (step > n - a) ? n : a + step;                   // no 32-bit overflow
+            if (b >= n) { b = n; break; }
+            if ((K(b) >> sh) != pfx) break;
+            a = b; step <<= 1;
+        }
+        int32_t lo = a + 1;
+        while (lo < b) { const int32_t mid = (int32_t)(((uint32_t)lo + (uint32_t)b) >> 1); if ((K(mid) >> sh) == pfx) lo = mid + 1; else b = mid; }
+        e = lo;
+    }
+    const int shc = sh - 2;
+    const int32_t quad = (int32_t)r + 1;
+
+    if (d == 0) {                                                // root record in quad 0
+        for (int k = 1; k < 4; ++k) { put(0, k, 0.f, 0.f, 0.f, -1.f, -1); aux[k] = NodeAux{0, 0}; }
+        const d3 t = psum[n];
+        if (t.a > 1e-15) put(0, 0, (float)(t.b / t.a), (float)(t.c / t.a), (float)t.a, (float)thr0, quad);
+        else put(0, 0, 0.f, 0.f, 0.f, -1.f, -1);
+        aux[0] = NodeAux{0, n};
+    }
+    // (size/theta)^2 of the children (depth d+1): exact power-of-four scaling
+    const float thr_child = (float)ldexp(thr0, -2 * (d + 1));
+
+    int32_t bc = i;
+    for (int c = 0; c < 4; ++c) {
+        int32_t bn;                                              // first body of the next child
+        if (c == 3) bn = e;
+        else {
+            const uint64_t target = (pfx << 2) | (uint64_t)(c + 1);
+            int32_t lo = bc, hb = e;
+            while (lo < hb) { const int32_t mid = (int32_t)(((uint32_t)lo + (uint32_t)hb) >> 1); if ((K(mid) >> shc) < target) lo = mid + 1; else hb = mid; }
+            bn = lo;
+        }
+        const int32_t nc = bn - bc;
+        float cx = 0.f, cy = 0.f, m = 0.f, thr = 0.f;            // leaves: thr = 0 (see the walk)
+        int32_t child = -1;
+        if (nc == 1) {
+            const float2 p = spos[bc];
+            cx = p.x; cy = p.y; m = smass[bc];
+        } else if (nc > 1) {
+            const d3 lo_s = psum[bc], hi_s = psum[bn];
+            const double mm = hi_s.a - lo_s.a;
+            m = (float)mm; cx = (float)((hi_s.b - lo_s.b) / mm); cy = (float)((hi_s.c - lo_s.c) / mm);
+            if (d + 1 == Dm) {                                   // depth-cap cell
+                if (!COMPAT) { thr = INFINITY; child = -(4 * quad + c) - 2; }
+            } else {                                             // subdivided cell
+                const int Lpc = (bc == 0) ? -1 : shared_levels(K(bc - 1), K(bc), Dm);
+                child = (int32_t)(off[bc] + (uint32_t)((d + 1) - (Lpc + 1))) + 1;
+                thr = thr_child;
+            }
+        }
+        if (!(m > 1e-15f)) { cx = 0.f; cy = 0.f; m = 0.f; thr = 0.f; child = -1; }   // project.cu:617
+        put(quad, c, cx, cy, m, thr, child);
+        aux[4 * quad + c] = NodeAux{bc, nc};
+        bc = bn;
     }
 }
 
@@ -357,27 +650,6 @@ __global__ __launch_bounds__(kBlock) void com_level_kernel(NodeD *__restrict__ g
     }
     if (tot > 0.0) { sx /= tot; sy /= tot; }
     gd[node].cx = sx; gd[node].cy = sy; gd[node].m = tot;
-}
-
-// ---- fp32 mode helpers ----------------------------------------------------------------------------
-// sorted copies for the walk + the (m, m*x, m*y) terms of the prefix sums
-template <typename Real2, typename Real>
-__global__ __launch_bounds__(kBlock) void gather_sorted_kernel(const uint32_t *__restrict__ perm,
-                                                                const Real2 *__restrict__ pos,
-                                                                const Real *__restrict__ mass,
-                                                                Real2 *__restrict__ spos,
-                                                                Real *__restrict__ smass,
-                                                                d3 *__restrict__ terms, int64_t n)
-{
-    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (s > n) return;
-    if (s == n) { terms[n] = d3{0.0, 0.0, 0.0}; return; }
-    const uint32_t i = perm[s];
-    const Real2 p = pos[i];
-    const Real m = mass[i];
-    spos[s] = p;
-    smass[s] = m;
-    terms[s] = d3{(double)m, (double)m * (double)p.x, (double)m * (double)p.y};
 }
 
 }  // namespace bh

@@ -8,11 +8,13 @@
 
 namespace bh {
 
-struct NodeF;
+struct QuadF;
+struct NodeAux;
 struct TreeCounters;
 
 struct WalkFastArgs {
-    const NodeF *nodes;
+    const QuadF *quads;        // quad 0 = root
+    const NodeAux *aux;        // per node: sorted body range (bucket leaves)
     const float2 *spos;        // positions in Morton-sorted order
     const float *smass;        // masses in sorted order (bucket leaves only)
     const uint32_t *perm;      // sorted index -> caller index
@@ -20,11 +22,14 @@ struct WalkFastArgs {
     float2 *spos_out, *svel;   // sorted-order outputs (integrate && to_sorted)
     float2 *acc_out;           // caller-order accelerations, may be null
     TreeCounters *ctr;
+    double *partial;           // per-workgroup min/max of the new positions, may be null
     int64_t lo, hi;            // sorted range walked by this launch
     float G, dt;
     int integrate, to_sorted;
+    uint32_t nblocks, xcd_chunk;   // filled by the launcher
 };
 
-hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, hipStream_t st);
+hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, bool pipelined, bool xcd,
+                            hipStream_t st);
 
 }  // namespace bh

@@ -3,11 +3,12 @@
 // (project.cu:819-836); designed for CDNA4 wave64, not translated from them.
 //
 //   * one wavefront = 64 Morton-adjacent bodies, one per lane; the traversal state is
-//     wave-uniform, so node reads are scalar loads (s_load_dwordx8 through the scalar data cache)
-//     broadcast to all lanes for free -- the reference's per-thread walk re-reads each 96-byte
-//     node once per body (project.cu:726), this reads a 32-byte record once per wave;
-//   * the four children of a subdivided cell are contiguous (one 128-byte line) and are evaluated
-//     together: one dependent memory round trip per opened cell instead of one per node;
+//     wave-uniform, so node reads are scalar loads (through the scalar data cache) broadcast to all
+//     lanes for free -- the reference's per-thread walk re-reads each 96-byte node once per body
+//     (project.cu:726), this reads 20 bytes per node once per wave;
+//   * the four children of a subdivided cell are one 80-byte structure-of-arrays record and are
+//     evaluated together: one memory round trip per opened cell instead of one per node, and that
+//     round trip is overlapped with the evaluation of the previous quad (see the kernel);
 //   * a stack entry is {first child, 64-bit lane mask of the bodies that opened the parent}.  The
 //     default stack lives in three VGPRs addressed by lane (v_writelane/v_readlane): entry k sits
 //     in lane k, so push/pop are single VALU instructions with no LDS round trip.  The LDS
@@ -22,6 +23,7 @@
 //     perm), or into the sorted arrays for the multi-GPU exchange.
 #include "bh_prims.hpp"
 #include "bh_nodes.hpp"
+#include "bh_bounds.hpp"
 #include "bh_walk_fast.h"
 
 namespace bh {
@@ -40,99 +42,113 @@ __device__ __forceinline__ const T BH_CONSTANT *as_constant(const T *p)
 #pragma clang diagnostic pop
 }
 
-// one 32-byte node through the scalar data cache (s_load_dwordx8): the address is wave-uniform
-typedef int32_t v8i __attribute__((ext_vector_type(8)));
+// one sibling quad (80 B, structure of arrays) through the scalar data cache: s_load_dwordx16 +
+// s_load_dwordx4 at a wave-uniform address
+typedef int32_t v16i __attribute__((ext_vector_type(16)));
+typedef int32_t v4i __attribute__((ext_vector_type(4)));
 typedef int32_t v2i __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ NodeF load_node(const NodeF BH_CONSTANT *p)
-{
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wold-style-cast"
-    const v8i r = *(const v8i BH_CONSTANT *)p;
-#pragma clang diagnostic pop
-    NodeF q;
-    q.cx = __int_as_float(r[0]); q.cy = __int_as_float(r[1]);
-    q.m = __int_as_float(r[2]);  q.thr = __int_as_float(r[3]);
-    q.child = r[4]; q.first = r[5]; q.count = r[6]; q.pad = r[7];
-    return q;
-}
+struct QuadRegs { v16i g; v4i c; };
 
-typedef int32_t v32i __attribute__((ext_vector_type(32)));
-__device__ __forceinline__ void load_quad(const NodeF BH_CONSTANT *p, NodeF (&q)[4])
+__device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
 {
+    QuadRegs r;
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wold-style-cast"
-    const v32i r = *(const v32i BH_CONSTANT *)p;
+    r.g = *(const v16i BH_CONSTANT *)q;
+    r.c = *(const v4i BH_CONSTANT *)((const char BH_CONSTANT *)q + 64);
 #pragma clang diagnostic pop
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        q[k].cx = __int_as_float(r[8 * k + 0]); q[k].cy = __int_as_float(r[8 * k + 1]);
-        q[k].m = __int_as_float(r[8 * k + 2]);  q[k].thr = __int_as_float(r[8 * k + 3]);
-        q[k].child = r[8 * k + 4]; q[k].first = r[8 * k + 5]; q[k].count = r[8 * k + 6];
-        q[k].pad = r[8 * k + 7];
-    }
+    return r;
 }
 
 constexpr int kLdsStackDepth = 128;   // 3*31+4 entries worst case
 
-// The loop body is written so that hipcc emits straight-line code per child: the push is an
-// unconditional write of {child, open mask} into the slot above the top followed by
-// `sp += (open != 0)`, so there is no control-flow merge (and none of the register copies it
-// costs) around the stack registers; lane masks stay in SGPR pairs (inverse_ballot / ballot);
-// the only branch per child is the integer "cell is empty" test.
-template <bool LDS_STACK, bool STATS>
+// Per child: one v_cmp decides accept/open/self (see eval); lane masks stay in SGPR pairs; the
+// three-register stack write happens only for nodes that some lane opens (uniform branches).
+//
+// The loop is software-pipelined over two register sets: while quad A is evaluated, the scalar
+// loads of the next stack entry (quad B) are already in flight, and vice versa, so a wave exposes
+// a load latency only when an evaluation starts from an empty stack.  (fp32 mode does not need
+// the reference's visiting order, so taking an entry off the stack before the current quad has
+// pushed its children is allowed.)
+template <bool LDS_STACK, bool STATS, bool PIPE>
 __global__ __launch_bounds__(kBlock) void walk_fast_kernel(WalkFastArgs a)
 {
     __shared__ int32_t s_base[LDS_STACK ? kWavesPerBlock : 1][LDS_STACK ? kLdsStackDepth : 1];
     __shared__ uint64_t s_mask[LDS_STACK ? kWavesPerBlock : 1][LDS_STACK ? kLdsStackDepth : 1];
 
     if (a.ctr->overflow) return;
+    // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each
+    // with its own 4 MiB L2.  Giving XCD x the x-th CONTIGUOUS eighth of the Morton order makes
+    // every L2 cache one spatial region's subtree instead of the whole tree.  Speed only: any
+    // placement gives the same result.
+    const uint32_t lb = a.xcd_chunk ? (blockIdx.x & 7u) * a.xcd_chunk + (blockIdx.x >> 3) : blockIdx.x;
+    if (lb >= a.nblocks) return;
     const int lane = lane_id(), w = wave_id();
-    const int64_t s = a.lo + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t s = a.lo + (int64_t)lb * kBlock + threadIdx.x;
     const bool valid = s < a.hi;
     const float2 p = valid ? a.spos[s] : float2{0.f, 0.f};
     float ax = 0.f, ay = 0.f;
     unsigned long long n_vis = 0, n_int = 0, n_wave = 0;
 
-    const NodeF BH_CONSTANT *nodes = as_constant(a.nodes);
+    const QuadF BH_CONSTANT *quads = as_constant(a.quads);
+    const NodeAux BH_CONSTANT *aux = as_constant(a.aux);
     const float2 BH_CONSTANT *cpos = as_constant(a.spos);
     const float BH_CONSTANT *cmass = as_constant(a.smass);
 
     int32_t v_base = 0, v_lo = 0, v_hi = 0;      // register-lane stack: entry k lives in lane k
     int sp = 0;                                   // wave-uniform
 
-    auto eval = [&](const NodeF q, const uint64_t mask) {
-        if (q.count == 0) return;                           // empty cell (project.cu:617)
-        const float dx = q.cx - p.x, dy = q.cy - p.y;
+    auto eval = [&](const float cx, const float cy, const int32_t mbits, const float thr, const int32_t child,
+                    const uint64_t mask) {
+        if (mbits == 0) return;                             // empty cell (project.cu:617): scalar int test
+        const float m = __int_as_float(mbits);
+        const float dx = cx - p.x, dy = cy - p.y;
         const float d2 = fmaf(dx, dx, dy * dy);
-        // lane masks as 64-bit scalars: a v_cmp result IS its ballot, so the algebra below is SALU
-        const uint64_t farm = __ballot(d2 > q.thr);         // leaves: thr = -1; buckets: +inf
-        // d2 > 0 is the self skip (project.cu:646): a single-body leaf carries the body's own
-        // position.  It also drops an exactly coincident second body, where the reference divides
-        // by zero (inf*0 -> NaN, project.cu:651-658): fp32 positions are quantised, so that case
-        // is reachable here and one NaN would poison the root box of every later step.
-        const uint64_t accm = mask & farm & __ballot(d2 > 0.f);
-        const uint64_t open = mask & ~farm;                 // never set for leaves
+        // One compare decides everything (a v_cmp result IS its ballot, so the rest is SALU):
+        //   subdivided cell: thr = (size/theta)^2  -> the reference's MAC, per body (project.cu:643)
+        //   leaf:            thr = 0               -> accepted unless d2 == 0, i.e. unless it is the
+        //                                             body itself (the self skip, project.cu:646) or an
+        //                                             exactly coincident body, where the reference divides
+        //                                             by zero (inf*0 -> NaN, project.cu:651-658); fp32
+        //                                             positions are quantised, that case is reachable, and
+        //                                             one NaN would poison the root box of every later step
+        //   bucket:          thr = +inf            -> accepted by nobody, opened by everybody
+        const uint64_t farm = __ballot(d2 > thr);
+        const uint64_t accm = mask & farm;
         const float ri = __builtin_amdgcn_rsqf(d2);
-        const float wgt = __builtin_amdgcn_inverse_ballot_w64(accm) ? q.m * ri * ri * ri : 0.f;
+        const float wgt = __builtin_amdgcn_inverse_ballot_w64(accm) ? m * ri * ri * ri : 0.f;
         ax = fmaf(wgt, dx, ax);
         ay = fmaf(wgt, dy, ay);
         if (STATS) { n_vis += __popcll(mask); ++n_wave; n_int += __popcll(accm); }
-        if (LDS_STACK) {
-            if (lane == 0) { s_base[w][sp] = q.child; s_mask[w][sp] = open; }
-        } else {
-            v_base = bh_writelane_i32(q.child, sp, v_base);
-            v_lo = bh_writelane_i32((int32_t)(uint32_t)open, sp, v_lo);
-            v_hi = bh_writelane_i32((int32_t)(uint32_t)(open >> 32), sp, v_hi);
+        if (child != -1) {                                  // subdivided cell or bucket reference
+            const uint64_t open = mask & ~farm;
+            if (open != 0) {                                // ~30 % of the evaluated nodes
+                if (LDS_STACK) {
+                    if (lane == 0) { s_base[w][sp] = child; s_mask[w][sp] = open; }
+                } else {
+                    v_base = bh_writelane_i32(child, sp, v_base);
+                    v_lo = bh_writelane_i32((int32_t)(uint32_t)open, sp, v_lo);
+                    v_hi = bh_writelane_i32((int32_t)(uint32_t)(open >> 32), sp, v_hi);
+                }
+                ++sp;
+            }
         }
-        sp += (open != 0) ? 1 : 0;
+    };
+
+    auto eval_quad = [&](const QuadRegs &q, const uint64_t mask) {
+        eval(__int_as_float(q.g[0]), __int_as_float(q.g[1]), q.g[8], __int_as_float(q.g[12]), q.c[0], mask);
+        eval(__int_as_float(q.g[2]), __int_as_float(q.g[3]), q.g[9], __int_as_float(q.g[13]), q.c[1], mask);
+        eval(__int_as_float(q.g[4]), __int_as_float(q.g[5]), q.g[10], __int_as_float(q.g[14]), q.c[2], mask);
+        eval(__int_as_float(q.g[6]), __int_as_float(q.g[7]), q.g[11], __int_as_float(q.g[15]), q.c[3], mask);
     };
 
     // depth-cap cell holding several bodies (compat off): summed body by body for the lanes that
     // reached it; self and exactly coincident bodies contribute nothing (d2 == 0)
-    auto bucket = [&](const NodeF q, const uint64_t mask) {
-        for (int32_t j = q.first; j < q.first + q.count; ++j) {
+    auto bucket = [&](const int32_t node, const uint64_t mask) {
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wold-style-cast"
+        const v2i rng = *(const v2i BH_CONSTANT *)(aux + node);
+        for (int32_t j = rng[0]; j < rng[0] + rng[1]; ++j) {
             const v2i ob = *(const v2i BH_CONSTANT *)(cpos + j);      // scalar loads: j is uniform
             const float om = *(const float BH_CONSTANT *)(cmass + j);
 #pragma clang diagnostic pop
@@ -147,35 +163,59 @@ __global__ __launch_bounds__(kBlock) void walk_fast_kernel(WalkFastArgs a)
         }
     };
 
-    eval(load_node(nodes), __ballot(valid));
+    // take the next quad entry off the stack; bucket references (-(node id) - 2) are served on the
+    // way; returns false when the stack is empty
+    auto pop_quad = [&](int32_t &base, uint64_t &mask) -> bool {
+        while (sp > 0) {
+            --sp;
+            if (LDS_STACK) {
+                base = __builtin_amdgcn_readfirstlane(s_base[w][sp]);
+                const uint64_t m = s_mask[w][sp];
+                mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(m >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)m);
+            } else {
+                base = __builtin_amdgcn_readlane(v_base, sp);
+                mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v_hi, sp) << 32) |
+                       (uint32_t)__builtin_amdgcn_readlane(v_lo, sp);
+            }
+            if (base >= 0) return true;
+            if (base <= -2) bucket(-base - 2, mask);       // base == -1 (a leaf opened by a NaN) is dropped
+        }
+        return false;
+    };
 
-    while (sp > 0) {
-        --sp;
-        int32_t base;
-        uint64_t mask;
-        if (LDS_STACK) {
-            base = __builtin_amdgcn_readfirstlane(s_base[w][sp]);
-            const uint64_t m = s_mask[w][sp];
-            mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(m >> 32)) << 32) |
-                   (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)m);
-        } else {
-            base = __builtin_amdgcn_readlane(v_base, sp);
-            mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v_hi, sp) << 32) |
-                   (uint32_t)__builtin_amdgcn_readlane(v_lo, sp);
+    if (PIPE) {
+        int32_t baseA = 0, baseB = 0;
+        uint64_t maskA = __ballot(valid), maskB = 0;
+        QuadRegs A = load_quad(quads), B;                   // quad 0: the root in slot 0
+        for (;;) {
+            // ---- A in hand: start the loads of the next entry, then evaluate A
+            const bool preB = pop_quad(baseB, maskB);
+            if (preB) B = load_quad(quads + baseB);
+            eval_quad(A, maskA);
+            if (!preB) {
+                if (!pop_quad(baseB, maskB)) break;
+                B = load_quad(quads + baseB);
+            }
+            // ---- B in hand
+            const bool preA = pop_quad(baseA, maskA);
+            if (preA) A = load_quad(quads + baseA);
+            eval_quad(B, maskB);
+            if (!preA) {
+                if (!pop_quad(baseA, maskA)) break;
+                A = load_quad(quads + baseA);
+            }
         }
-        if (base < 0) {                                     // bucket reference: -(node id) - 2
-            bucket(load_node(nodes + (-base - 2)), mask);
-            continue;
-        }
-        // the sibling quad is one 128-byte line: both s_load_dwordx16 are issued before any use
-        NodeF q[4];
-        load_quad(nodes + base, q);
-        eval(q[0], mask);
-        eval(q[1], mask);
-        eval(q[2], mask);
-        eval(q[3], mask);
+    } else {
+        int32_t base = 0;
+        uint64_t mask = __ballot(valid);
+        do {
+            const QuadRegs q = load_quad(quads + base);
+            eval_quad(q, mask);
+        } while (pop_quad(base, mask));
     }
 
+    float2 np = p;
     if (valid) {
         const float gx = a.G * ax, gy = a.G * ay;
         const uint32_t body = a.perm[s];
@@ -184,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void walk_fast_kernel(WalkFastArgs a)
             float2 v = a.vel[body];
             v.x = fmaf(gx, a.dt, v.x);
             v.y = fmaf(gy, a.dt, v.y);
-            float2 np{fmaf(v.x, a.dt, p.x), fmaf(v.y, a.dt, p.y)};
+            np = float2{fmaf(v.x, a.dt, p.x), fmaf(v.y, a.dt, p.y)};
             if (a.to_sorted) {
                 a.svel[s] = v;
                 a.spos_out[s] = np;
@@ -194,6 +234,8 @@ __global__ __launch_bounds__(kBlock) void walk_fast_kernel(WalkFastArgs a)
             }
         }
     }
+    // min/max of the new positions per workgroup: the next step's root box needs no body pass
+    if (a.partial) block_bounds_to_partial(valid, (double)np.x, (double)np.y, a.partial + 4 * (size_t)lb);
     if (STATS && lane == 0) {
         atomicAdd(&a.ctr->visits, n_vis);
         atomicAdd(&a.ctr->interactions, n_int);
@@ -201,20 +243,32 @@ __global__ __launch_bounds__(kBlock) void walk_fast_kernel(WalkFastArgs a)
     }
 }
 
-template <bool L, bool S>
-static hipError_t launch(const WalkFastArgs &a, hipStream_t st)
+template <bool L, bool S, bool P>
+static hipError_t launch(WalkFastArgs a, bool xcd, hipStream_t st)
 {
     const int64_t cnt = a.hi - a.lo;
     if (cnt <= 0) return hipSuccess;
-    const unsigned grid = (unsigned)((cnt + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL((walk_fast_kernel<L, S>), dim3(grid), dim3(kBlock), 0, st, a);
+    a.nblocks = (uint32_t)((cnt + kBlock - 1) / kBlock);
+    a.xcd_chunk = xcd ? (a.nblocks + 7) / 8 : 0;
+    const unsigned grid = xcd ? 8 * a.xcd_chunk : a.nblocks;
+    hipLaunchKernelGGL((walk_fast_kernel<L, S, P>), dim3(grid), dim3(kBlock), 0, st, a);
     return hipGetLastError();
 }
 
-hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, hipStream_t st)
+hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, bool pipelined, bool xcd,
+                            hipStream_t st)
 {
-    if (lds_stack) return stats ? launch<true, true>(a, st) : launch<true, false>(a, st);
-    return stats ? launch<false, true>(a, st) : launch<false, false>(a, st);
+    const int key = (lds_stack ? 4 : 0) | (stats ? 2 : 0) | (pipelined ? 1 : 0);
+    switch (key) {
+    case 0: return launch<false, false, false>(a, xcd, st);
+    case 1: return launch<false, false, true>(a, xcd, st);
+    case 2: return launch<false, true, false>(a, xcd, st);
+    case 3: return launch<false, true, true>(a, xcd, st);
+    case 4: return launch<true, false, false>(a, xcd, st);
+    case 5: return launch<true, false, true>(a, xcd, st);
+    case 6: return launch<true, true, false>(a, xcd, st);
+    default: return launch<true, true, true>(a, xcd, st);
+    }
 }
 
 }  // namespace bh
