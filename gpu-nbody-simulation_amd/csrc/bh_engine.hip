@@ -56,6 +56,7 @@ struct bh_ctx {
     uint64_t *keys_sorted = nullptr;
     uint32_t *perm = nullptr;
     uint32_t *radix_counts = nullptr, *bsum_sort = nullptr, *bsum_u32 = nullptr, *cnt = nullptr;
+    uint64_t *coarse = nullptr;          // fp32: every 256th sorted key
     uint32_t *cell_first = nullptr;      // fp32: rank of a subdivided cell -> its first sorted body
     d3 *terms = nullptr, *bsum_d3 = nullptr;
     double *partial = nullptr, *box = nullptr;
@@ -124,17 +125,6 @@ void owned_range(const bh_ctx *c, int64_t *lo, int64_t *hi)
     *hi = std::min<int64_t>(c->n, chunk * (c->rank + 1));
 }
 
-// exclusive scan of `len` uint32 in place (three launches)
-int enqueue_scan_u32(bh_ctx *c, uint32_t *data, int64_t len)
-{
-    if (len <= 0) return BH_OK;
-    const unsigned nb = blocks_for(len, kTile);
-    hipLaunchKernelGGL((scan_tile_sums<uint32_t>), dim3(nb), dim3(kBlock), 0, c->stream, data, c->bsum_sort, len);
-    hipLaunchKernelGGL((scan_top<uint32_t>), dim3(1), dim3(kBlock), 0, c->stream, c->bsum_sort, (int)nb, (uint32_t *)nullptr);
-    hipLaunchKernelGGL((scan_apply<uint32_t>), dim3(nb), dim3(kBlock), 0, c->stream, data, data, c->bsum_sort, len);
-    return BH_OK;
-}
-
 template <bool EXACT>
 int enqueue_build_t(bh_ctx *c)
 {
@@ -166,10 +156,11 @@ int enqueue_build_t(bh_ctx *c)
             const int shift = p * kRadixBits;
             hipLaunchKernelGGL(radix_hist, dim3(nbl), dim3(kBlock), 0, st, c->keys[cur], c->radix_counts, n, shift,
                                (int)nbl);
-            int rc = enqueue_scan_u32(c, c->radix_counts, (int64_t)kRadix * nbl);
-            if (rc) return rc;
+            hipLaunchKernelGGL(radix_rowscan, dim3(kRadix), dim3(kBlock), 0, st, c->radix_counts, c->bsum_sort,
+                               (int)nbl);
             hipLaunchKernelGGL(radix_scatter, dim3(nbl), dim3(kBlock), 0, st, c->keys[cur], c->vals[cur],
-                               c->keys[cur ^ 1], c->vals[cur ^ 1], c->radix_counts, n, shift, (int)nbl);
+                               c->keys[cur ^ 1], c->vals[cur ^ 1], c->radix_counts, c->bsum_sort, n, shift,
+                               (int)nbl);
             cur ^= 1;
         }
         c->keys_sorted = c->keys[cur];
@@ -180,7 +171,7 @@ int enqueue_build_t(bh_ctx *c)
         const unsigned nbs = blocks_for(n + 1, kTile);
         hipLaunchKernelGGL((prep_kernel<EXACT, Real2, Real>), dim3(nbs), dim3(kBlock), 0, st, c->keys_sorted,
                            c->perm, pos, mass, c->cnt, c->bsum_u32, (Real2 *)c->spos, (Real *)c->smass, c->terms,
-                           c->bsum_d3, n, Dm);
+                           c->bsum_d3, c->coarse, n, Dm);
         hipLaunchKernelGGL(scan_top2, dim3(EXACT ? 1 : 2), dim3(kBlock), 0, st, c->bsum_u32, c->bsum_d3, (int)nbs,
                            c->ctr);
         hipLaunchKernelGGL((scan_apply2<EXACT>), dim3(nbs), dim3(kBlock), 0, st, c->cnt, c->bsum_u32, c->terms,
@@ -201,11 +192,11 @@ int enqueue_build_t(bh_ctx *c)
         const int64_t span = std::max<int64_t>(1, std::min<int64_t>(c->internal_cap, std::max<int64_t>(n - 1, 0) * (int64_t)std::max(1, Dm)));
         const unsigned nbc = blocks_for(span, kBlock);
         if (c->compat)
-            hipLaunchKernelGGL((nodes_fast_kernel<true>), dim3(nbc), dim3(kBlock), 0, st, c->keys_sorted, c->cnt,
+            hipLaunchKernelGGL((nodes_fast_kernel<true>), dim3(nbc), dim3(kBlock), 0, st, c->keys_sorted, c->coarse, c->cnt,
                                c->cell_first, c->spos, c->smass, c->box, c->terms, n, Dm, c->cfg.theta,
                                c->internal_cap, c->qf, c->aux, c->ctr);
         else
-            hipLaunchKernelGGL((nodes_fast_kernel<false>), dim3(nbc), dim3(kBlock), 0, st, c->keys_sorted, c->cnt,
+            hipLaunchKernelGGL((nodes_fast_kernel<false>), dim3(nbc), dim3(kBlock), 0, st, c->keys_sorted, c->coarse, c->cnt,
                                c->cell_first, c->spos, c->smass, c->box, c->terms, n, Dm, c->cfg.theta,
                                c->internal_cap, c->qf, c->aux, c->ctr);
     }
@@ -334,7 +325,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     A(&c->cnt, cap + 1);
     { const size_t nbl = blocks_for(cap, kTile);
       A(&c->radix_counts, (size_t)kRadix * nbl);
-      A(&c->bsum_sort, blocks_for((int64_t)kRadix * nbl, kTile) + 8); }
+      A(&c->bsum_sort, kRadix + 8); }
     A(&c->bsum_u32, blocks_for(cap + 1, kTile) + 8);
     A(&c->partial, 4 * (std::max<size_t>(1024, blocks_for(cap, kBlock)) + 2)); A(&c->box, 4);
     A(&c->ctr, 1);
@@ -344,6 +335,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     } else {
         A(&c->qf, c->internal_cap + 1); A(&c->aux, 4 * (c->internal_cap + 1));
         A(&c->cell_first, c->internal_cap + 1);
+        A(&c->coarse, cap / 256 + 2);
         A(&c->spos, cap); A(&c->spos_out, cap + 1024); A(&c->svel, cap + 1024); A(&c->smass, cap);
         A(&c->terms, cap + 1); A(&c->bsum_d3, blocks_for(cap + 1, kTile) + 8);
     }

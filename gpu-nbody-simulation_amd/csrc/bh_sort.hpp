@@ -2,8 +2,11 @@
 // three-kernel exclusive scan it uses.  Included by the engine translation unit only.
 //
 //   radix_hist    : counts[digit * nblocks + block] = occurrences of digit in tile `block`
-//   scan (3 launches) of counts in digit-major order => global base of every (digit, block)
-//   radix_scatter : stable scatter of the tile using per-round ballot matching
+//   radix_rowscan : one workgroup per digit: exclusive prefix along its row, row total aside
+//   radix_scatter : base(digit, block) = exclusive scan of the 256 row totals (done in-kernel)
+//                   + row prefix; stable scatter of the tile using per-round ballot matching
+// Three launches per pass (it was five with a generic three-kernel scan of the count matrix; every
+// launch costs ~6 us here, so the scan launches cost more than the sorting itself).
 // A round handles 256 consecutive elements (thread t <-> element round*256 + t), so ranks follow
 // element order and equal keys keep their input order.
 //
@@ -69,6 +72,25 @@ __global__ __launch_bounds__(kBlock) void scan_apply(const T *in, T *out, const 
 }
 
 constexpr int kRadixBits = 8;
+
+// grid = 256 workgroups (one per digit): counts[d][*] -> exclusive prefix in place, total aside
+__global__ __launch_bounds__(kBlock) void radix_rowscan(uint32_t *__restrict__ counts,
+                                                         uint32_t *__restrict__ row_total, int nblocks)
+{
+    __shared__ uint32_t sm[kWavesPerBlock + 1];
+    uint32_t *row = counts + (int64_t)blockIdx.x * nblocks;
+    uint32_t carry = 0;
+    for (int c0 = 0; c0 < nblocks; c0 += kBlock) {
+        const int b = c0 + threadIdx.x;
+        const uint32_t v = (b < nblocks) ? row[b] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_sum(v, sm, tot);
+        if (b < nblocks) row[b] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
+}
+
 constexpr int kRadix = 1 << kRadixBits;
 static_assert(kRadix == kBlock, "one thread per digit");
 
@@ -93,14 +115,20 @@ __global__ __launch_bounds__(kBlock) void radix_scatter(const uint64_t *__restri
                                                          const uint32_t *__restrict__ vin,
                                                          uint64_t *__restrict__ kout,
                                                          uint32_t *__restrict__ vout,
-                                                         const uint32_t *__restrict__ offs, int64_t n,
+                                                         const uint32_t *__restrict__ offs,
+                                                         const uint32_t *__restrict__ row_total, int64_t n,
                                                          int shift, int nblocks)
 {
     __shared__ uint32_t run[kRadix];
     __shared__ uint32_t wcnt[kWavesPerBlock][kRadix];
     __shared__ uint32_t gbase[kRadix];
+    __shared__ uint32_t sm[kWavesPerBlock + 1];
     const int t = threadIdx.x, w = wave_id(), l = lane_id();
-    gbase[t] = offs[(int64_t)t * nblocks + blockIdx.x];
+    {
+        uint32_t all;
+        const uint32_t digit_base = block_exclusive_sum(row_total[t], sm, all);
+        gbase[t] = digit_base + offs[(int64_t)t * nblocks + blockIdx.x];
+    }
     run[t] = 0;
 #pragma unroll
     for (int k = 0; k < kWavesPerBlock; ++k) wcnt[k][t] = 0;

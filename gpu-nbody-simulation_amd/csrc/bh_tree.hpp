@@ -38,6 +38,11 @@
 
 namespace bh {
 
+// every kCoarse-th sorted key: a 32 KB index at N = 1M that stays hot in L2, so the range search
+// of a LARGE cell costs ~12 hot loads + 8 more instead of ~40 cold ones (those searches are the
+// critical path of the node kernel: the few cells near the root)
+constexpr int kCoarse = 256;
+
 __device__ __forceinline__ int shared_levels(uint64_t a, uint64_t b, int Dm)
 {
     const uint64_t x = a ^ b;
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void prep_kernel(const uint64_t *__restrict
                                                        uint32_t *__restrict__ bsum_u32,
                                                        Real2 *__restrict__ spos, Real *__restrict__ smass,
                                                        d3 *__restrict__ terms, d3 *__restrict__ bsum_d3,
-                                                       int64_t n, int Dm)
+                                                       uint64_t *__restrict__ coarse, int64_t n, int Dm)
 {
     __shared__ uint32_t smu[kWavesPerBlock + 1];
     __shared__ d3 smd[kWavesPerBlock + 1];
@@ -170,6 +175,7 @@ __global__ __launch_bounds__(kBlock) void prep_kernel(const uint64_t *__restrict
             }
             cnt[i] = c;
             csum += c;
+            if (!EXACT && (i & (kCoarse - 1)) == 0) coarse[i / kCoarse] = keys[i];   // sampled index
             if (!EXACT) {
                 const uint32_t b = perm[i];
                 const Real2 p = pos[b];
@@ -494,8 +500,9 @@ constexpr int kKeyWin = kBlock + 1 + kKeyHalo;
 
 template <bool COMPAT>
 __global__ __launch_bounds__(kBlock, 8) void nodes_fast_kernel(
-    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ off,
-    const uint32_t *__restrict__ cell_first, const float2 *__restrict__ spos,
+    const uint64_t *__restrict__ keys, const uint64_t *__restrict__ coarse,
+    const uint32_t *__restrict__ off, const uint32_t *__restrict__ cell_first,
+    const float2 *__restrict__ spos,
     const float *__restrict__ smass, const double *__restrict__ box, const d3 *__restrict__ psum,
     int64_t n64, int Dm, double theta, int64_t internal_cap, QuadF *__restrict__ qf,
     NodeAux *__restrict__ aux, TreeCounters *ctr)
@@ -504,14 +511,25 @@ __global__ __launch_bounds__(kBlock, 8) void nodes_fast_kernel(
     // from its position in that body's chain.  32-bit indices throughout (bh_create caps n < 2^31).
     __shared__ uint64_t wkeys[kKeyWin];
     __shared__ int32_t s_wlo;
+    // The 256 quads of a workgroup are contiguous in memory (quad = rank + 1): they are assembled
+    // in LDS and written out with coalesced 16-byte stores.  Storing field by field from the
+    // owning lanes costs 24 scattered 4-byte stores per cell -- 18 M separate L2 write requests at
+    // N = 1M, which was most of this kernel's time.
+    __shared__ __attribute__((aligned(16))) int32_t stage_q[kBlock * 20];
+    __shared__ __attribute__((aligned(16))) int32_t stage_a[kBlock * 8];
     const int32_t n = (int32_t)n64;
     const uint32_t total = ctr->n_internal;
     float *qw = reinterpret_cast<float *>(qf);                  // 20 dwords per quad
     int32_t *qi = reinterpret_cast<int32_t *>(qf);
-    auto put = [&](int32_t quad, int slot, float cx, float cy, float m, float thr, int32_t child) {
+    auto put = [&](int32_t quad, int slot, float cx, float cy, float m, float thr, int32_t child) {   // direct
         const int64_t o = (int64_t)quad * 20;
         qw[o + 2 * slot] = cx; qw[o + 2 * slot + 1] = cy; qw[o + 8 + slot] = m; qw[o + 12 + slot] = thr;
         qi[o + 16 + slot] = child;
+    };
+    auto put_lds = [&](int slot, float cx, float cy, float m, float thr, int32_t child) {             // staged
+        int32_t *o = stage_q + threadIdx.x * 20;
+        o[2 * slot] = __float_as_int(cx); o[2 * slot + 1] = __float_as_int(cy);
+        o[8 + slot] = __float_as_int(m); o[12 + slot] = __float_as_int(thr); o[16 + slot] = child;
     };
 
     if (total == 0) {
@@ -551,8 +569,23 @@ __global__ __launch_bounds__(kBlock, 8) void nodes_fast_kernel(
         return (k >= 0 && k < kKeyWin) ? wkeys[k] : keys[j];
     };
 
+    // first j in [lo, hi) with (key_j >> sh) >= target.  Large ranges are narrowed on the sampled
+    // index first: after that the remaining range is < 2*kCoarse wide.
+    auto lower_bound = [&](int32_t lo, int32_t hi, int sh, uint64_t target) -> int32_t {
+        if (hi - lo > 4 * kCoarse) {
+            int32_t cl = (lo + kCoarse - 1) / kCoarse, ch = (hi - 1) / kCoarse + 1;   // samples inside [lo, hi)
+            // first sample index c in [cl, ch) with (coarse[c] >> sh) >= target
+            while (cl < ch) { const int32_t mid = (int32_t)(((uint32_t)cl + (uint32_t)ch) >> 1); if ((coarse[mid] >> sh) < target) cl = mid + 1; else ch = mid; }
+            const int32_t up = (cl * kCoarse < hi) ? cl * kCoarse : hi;              // key[up] >= target (or up == hi)
+            const int32_t dn = ((cl - 1) * kCoarse > lo) ? (cl - 1) * kCoarse : lo;  // key[dn] < target (or dn == lo)
+            lo = dn; hi = up;
+        }
+        while (lo < hi) { const int32_t mid = (int32_t)(((uint32_t)lo + (uint32_t)hi) >> 1); if ((K(mid) >> sh) < target) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+
     const uint32_t r = r_block + threadIdx.x;
-    if (r >= total) return;
+    if (r < total) {
     const int32_t i = (int32_t)cell_first[r];
     const uint64_t key = K(i);
     const int Lp = (i == 0) ? -1 : shared_levels(K(i - 1), key, Dm);
@@ -571,12 +604,14 @@ __global__ __launch_bounds__(kBlock, 8) void nodes_fast_kernel(
         for (;;) {
             b = (step > n - a) ? n : a + step;                   // no 32-bit overflow
             if (b >= n) { b = n; break; }
+            if (step > 2 * kCoarse) break;                       // large cell: let the index finish
             if ((K(b) >> sh) != pfx) break;
             a = b; step <<= 1;
         }
-        int32_t lo = a + 1;
-        while (lo < b) { const int32_t mid = (int32_t)(((uint32_t)lo + (uint32_t)b) >> 1); if ((K(mid) >> sh) == pfx) lo = mid + 1; else b = mid; }
-        e = lo;
+        // keys in (a, b) may be inside or outside; key[a] is inside.  (If the gallop stopped
+        // because the cell is large, b is not yet known to be outside: search up to n.)
+        if (step > 2 * kCoarse && b < n && (K(b) >> sh) == pfx) { a = b; b = n; }
+        e = lower_bound(a + 1, b, sh, pfx + 1);
     }
     const int shc = sh - 2;
     const int32_t quad = (int32_t)r + 1;
@@ -597,9 +632,7 @@ __global__ __launch_bounds__(kBlock, 8) void nodes_fast_kernel(
         if (c == 3) bn = e;
         else {
             const uint64_t target = (pfx << 2) | (uint64_t)(c + 1);
-            int32_t lo = bc, hb = e;
-            while (lo < hb) { const int32_t mid = (int32_t)(((uint32_t)lo + (uint32_t)hb) >> 1); if ((K(mid) >> shc) < target) lo = mid + 1; else hb = mid; }
-            bn = lo;
+            bn = lower_bound(bc, e, shc, target);
         }
         const int32_t nc = bn - bc;
         float cx = 0.f, cy = 0.f, m = 0.f, thr = 0.f;            // leaves: thr = 0 (see the walk)
@@ -620,9 +653,24 @@ __global__ __launch_bounds__(kBlock, 8) void nodes_fast_kernel(
             }
         }
         if (!(m > 1e-15f)) { cx = 0.f; cy = 0.f; m = 0.f; thr = 0.f; child = -1; }   // project.cu:617
-        put(quad, c, cx, cy, m, thr, child);
-        aux[4 * quad + c] = NodeAux{bc, nc};
+        put_lds(c, cx, cy, m, thr, child);
+        stage_a[threadIdx.x * 8 + 2 * c] = bc;
+        stage_a[threadIdx.x * 8 + 2 * c + 1] = nc;
         bc = bn;
+    }
+    }   // r < total
+
+    // coalesced write-out of this workgroup's quads [r_block + 1, r_block + 1 + cells)
+    __syncthreads();
+    const uint32_t cells = (total - r_block < (uint32_t)kBlock) ? total - r_block : (uint32_t)kBlock;
+    {
+        typedef int32_t v4 __attribute__((ext_vector_type(4)));
+        v4 *dq = reinterpret_cast<v4 *>(qi + ((int64_t)r_block + 1) * 20);
+        const v4 *sq = reinterpret_cast<const v4 *>(stage_q);
+        for (uint32_t k = threadIdx.x; k < cells * 5; k += kBlock) dq[k] = sq[k];
+        v4 *da = reinterpret_cast<v4 *>(aux + 4 * ((int64_t)r_block + 1));
+        const v4 *sa = reinterpret_cast<const v4 *>(stage_a);
+        for (uint32_t k = threadIdx.x; k < cells * 2; k += kBlock) da[k] = sa[k];
     }
 }
 
