@@ -32,7 +32,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
-NODE_BYTES = 32         # fp32 node record (bh_nodes.hpp NodeF)
+NODE_BYTES = 20         # fp32 node: one quarter of the 80-byte sibling-quad record (bh_nodes.hpp QuadF)
 
 
 def parse():
@@ -155,14 +155,25 @@ def main():
         u64 = ss.wave_nodes / n                      # distinct nodes per body per 64-body group
         # algorithmic bytes of ONE walk+integrate launch (DESIGN.md "Roofline"):
         #   per body: sorted pos 8 + perm 4 + vel r/w 16 + pos w 8 + accel w 8 = 44 B
-        #   per wave-node visit: one 32-byte node record
+        #   per wave-node visit: one 20-byte node (a quarter of an 80-byte quad record)
         walk_bytes = n * 44 + ss.wave_nodes * NODE_BYTES
         value = n * a.steps / elapsed
         roof = None
         if walk_ms:
             ach = walk_bytes / (walk_ms * 1e-3) / 1e9
+            # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+            # (profiles/latest_walk_traffic.json, written by scripts/summarize_profile.py; counters
+            # cannot be read from inside the process)
+            traffic, tsrc = None, None
+            try:
+                with open(os.path.join(ROOT, "profiles", "latest_walk_traffic.json")) as fh:
+                    tj = json.load(fh)
+                if n == 1 << 20 and a.init == "plummer":
+                    traffic, tsrc = tj["traffic_bytes"], tj["source"]
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                     "kernel": "walk_fast_kernel", "kernel_ms": walk_ms,
                     "algorithmic_bytes_per_launch": walk_bytes, "u64_nodes_per_body": u64}
         out = {

@@ -42,7 +42,7 @@ struct bh_ctx {
     bool uploaded = false, tree_valid = false;
     int64_t internal_cap = 0, node_cap = 0;
     int sort_passes = 0;
-    bool walk_pipelined = false, walk_xcd = false;  // BH_WALK_PIPE / BH_WALK_XCD override (A/B)
+    int walk_mode = 0; bool walk_xcd = false;  // BH_WALK_PIPE / BH_WALK_XCD override (A/B)
     int partial_count = 0;         // > 0: partial[] holds per-workgroup min/max of the current positions
 
     // caller-order state (double2/double or float2/float)
@@ -118,9 +118,12 @@ inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + pe
 
 void owned_range(const bh_ctx *c, int64_t *lo, int64_t *hi)
 {
-    // equal chunks of ceil(n/world) sorted slots (the last ranks may own fewer, or none), so the
-    // all_gather of the exchange moves one fixed-size block per rank
-    const int64_t chunk = (c->n + c->world - 1) / c->world;
+    // equal chunks of ceil(n/world) sorted slots rounded up to the workgroup size (the last ranks
+    // may own fewer, or none): every rank then forms exactly the wavefronts the single-GPU run
+    // forms, so per-body summation order -- and therefore every bit of the result -- does not
+    // depend on the number of GPUs; and the all_gather moves one fixed-size block per rank
+    const int64_t per = (c->n + c->world - 1) / c->world;
+    const int64_t chunk = (per + kBlock - 1) / kBlock * kBlock;
     *lo = std::min<int64_t>(c->n, chunk * c->rank);
     *hi = std::min<int64_t>(c->n, chunk * (c->rank + 1));
 }
@@ -244,7 +247,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted)
         a.integrate = integrate ? 1 : 0; a.to_sorted = to_sorted ? 1 : 0;
         // the register-lane stack holds 64 entries; the walk never needs more than 3*Dm + 2
         const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0 || (3 * c->Dm + 2 > kWave);
-        BH_HIP(c, launch_walk_fast(a, lds, stats, c->walk_pipelined, c->walk_xcd, c->stream));
+        BH_HIP(c, launch_walk_fast(a, lds, stats, c->walk_mode, c->walk_xcd, c->stream));
     }
     if (want_partial) c->partial_count = (int)blocks_for(hi - lo, kBlock);
     return BH_OK;
@@ -294,7 +297,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     c->compat = cfg->reference_compat != 0;
     c->device = cfg->device;
     c->sort_passes = (2 * c->Dm + kRadixBits - 1) / kRadixBits;
-    if (const char *e = std::getenv("BH_WALK_PIPE")) c->walk_pipelined = std::atoi(e) != 0;
+    if (const char *e = std::getenv("BH_WALK_PIPE")) c->walk_mode = std::atoi(e);
     if (const char *e = std::getenv("BH_WALK_XCD")) c->walk_xcd = std::atoi(e) != 0;
     auto bail = [&](int rc) { g_create_error = c->err; bh_destroy(c); return rc; };
 
@@ -336,7 +339,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
         A(&c->qf, c->internal_cap + 1); A(&c->aux, 4 * (c->internal_cap + 1));
         A(&c->cell_first, c->internal_cap + 1);
         A(&c->coarse, cap / 256 + 2);
-        A(&c->spos, cap); A(&c->spos_out, cap + 1024); A(&c->svel, cap + 1024); A(&c->smass, cap);
+        A(&c->spos, cap); A(&c->spos_out, cap + 64 * kBlock + 1024); A(&c->svel, cap + 64 * kBlock + 1024); A(&c->smass, cap);
         A(&c->terms, cap + 1); A(&c->bsum_d3, blocks_for(cap + 1, kTile) + 8);
     }
     if (rc) return bail(rc);
@@ -667,7 +670,7 @@ int bh_stats(bh_ctx *c, bh_stats_t *out)
 // ---- multi-GPU plumbing -------------------------------------------------------------------------
 int bh_set_owned_fraction(bh_ctx *c, int32_t rank, int32_t world)
 {
-    if (!c || world < 1 || rank < 0 || rank >= world) return fail(c, BH_ERR_ARG, "bh_set_owned_fraction: bad rank/world");
+    if (!c || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(c, BH_ERR_ARG, "bh_set_owned_fraction: bad rank/world (world <= 64)");
     c->rank = rank;
     c->world = world;
     return BH_OK;

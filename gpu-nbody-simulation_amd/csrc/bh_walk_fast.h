@@ -29,7 +29,8 @@ struct WalkFastArgs {
     uint32_t nblocks, xcd_chunk;   // filled by the launcher
 };
 
-hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, bool pipelined, bool xcd,
+// mode: 0 = one stack entry per iteration, 1 = software-pipelined, 2 = two entries per iteration
+hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, int mode, bool xcd,
                             hipStream_t st);
 
 }  // namespace bh

@@ -52,7 +52,8 @@ class ShardedStepper:
 
     def __init__(self, engine, rank: int, world: int, n: int, device: torch.device | None = None):
         self.eng, self.rank, self.world, self.n = engine, rank, world, n
-        self.chunk = (n + world - 1) // world
+        per = (n + world - 1) // world
+        self.chunk = (per + 255) // 256 * 256       # workgroup-aligned, as bh_owned_range computes it
         engine.set_owned_fraction(rank, world)
         lo, hi = engine.owned_range()
         assert (lo, hi) == (min(n, self.chunk * rank), min(n, self.chunk * (rank + 1)))

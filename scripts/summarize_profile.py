@@ -23,4 +23,22 @@ with open(f"{dst}/pmc_summary.csv", "w", newline="") as fh:
     w.writerow(["Kernel_Name", "Counter_Name", "Dispatches", "Mean_Value_Per_Dispatch"])
     for r in sorted(rows):
         w.writerow(r)
-print(open(f"{dst}/kernel_stats.csv").read()[:1500])
+# HBM traffic of the walk kernel per launch (MI355X_MICROARCH.md, HBM/rocprofv3): FETCH_SIZE and
+# WRITE_SIZE are in KB, collected in separate --pmc passes; on gfx950 FETCH_SIZE reports exactly 1/2
+# of the bytes read -- calibrated for THIS kernel's access pattern (wave-uniform 64-byte scalar
+# loads) with scripts/calib/fetch_calib.hip: ratio 0.50003 -- so reads = 2 * FETCH_SIZE.
+walk = {c: v for (k, c, n, v) in rows if k.startswith("void bh::walk_fast_kernel<false, false")}
+calib = {}
+for f in glob.glob(f"{src}/calib/*/*_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"].startswith("k_") and r["Counter_Name"] == "FETCH_SIZE":
+            calib[r["Kernel_Name"].split("(")[0]] = float(r["Counter_Value"]) * 1024 / 2**30
+if "FETCH_SIZE" in walk and "WRITE_SIZE" in walk:
+    t = {"kernel": "walk_fast_kernel", "fetch_size_kb": walk["FETCH_SIZE"], "write_size_kb": walk["WRITE_SIZE"],
+         "fetch_correction": 2.0, "traffic_bytes": 2.0 * walk["FETCH_SIZE"] * 1024 + walk["WRITE_SIZE"] * 1024,
+         "l2_hit_rate": walk.get("TCC_HIT_sum", 0) / max(1.0, walk.get("TCC_HIT_sum", 0) + walk.get("TCC_MISS_sum", 0)),
+         "calibration_fetch_size_over_true_bytes": calib, "source": os.path.basename(dst)}
+    json.dump(t, open(f"{dst}/walk_traffic.json", "w"), indent=1)
+    json.dump(t, open(os.path.join(os.path.dirname(dst.rstrip("/")), "latest_walk_traffic.json"), "w"), indent=1)
+    print(json.dumps(t))
+print(open(f"{dst}/kernel_stats.csv").read()[:1800])

@@ -31,12 +31,12 @@ class OracleStandInEngine:
 
     def set_owned_fraction(self, rank, world):
         self.rank, self.world = rank, world
-        chunk = (self.n + world - 1) // world
+        chunk = ((self.n + world - 1) // world + 255) // 256 * 256
         self.spos = torch.zeros(2 * chunk * world, dtype=torch.float32)
         self.svel = torch.zeros(2 * chunk * world, dtype=torch.float32)
 
     def owned_range(self):
-        chunk = (self.n + self.world - 1) // self.world
+        chunk = ((self.n + self.world - 1) // self.world + 255) // 256 * 256
         return min(self.n, chunk * self.rank), min(self.n, chunk * (self.rank + 1))
 
     def device_sorted(self):

@@ -51,7 +51,7 @@ def _worker(rank, world, port, n, steps, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [96, 101])          # divisible and not divisible by the world size
+@pytest.mark.parametrize("n", [512, 700])         # chunks of 256: full/full and full/partial
 def test_two_ranks_equal_one_rank(tmp_path, n):
     world, steps = 2, 2
     port = _free_port()
@@ -59,7 +59,7 @@ def test_two_ranks_equal_one_rank(tmp_path, n):
     r0 = np.load(tmp_path / "rank0.npz")
     r1 = np.load(tmp_path / "rank1.npz")
     # ownership: disjoint, contiguous, covering, fixed-size chunks of ceil(n/world)
-    chunk = (n + world - 1) // world
+    chunk = ((n + world - 1) // world + 255) // 256 * 256
     assert (int(r0["lo"]), int(r0["hi"])) == (0, chunk) and (int(r1["lo"]), int(r1["hi"])) == (chunk, n)
     # replicas agree after the exchange
     assert np.array_equal(r0["pos"], r1["pos"]) and np.array_equal(r0["vel"], r1["vel"])

@@ -20,7 +20,7 @@ def test_emulated_ranks_equal_single_context(n, world):
     ref = G.BarnesHutEngine(G.BhConfig(**cfg))
     ref.upload(p, v, m)
     engs = [G.BarnesHutEngine(G.BhConfig(**cfg)) for _ in range(world)]
-    chunk = (n + world - 1) // world
+    chunk = ((n + world - 1) // world + 255) // 256 * 256
     bufs = []
     for r, e in enumerate(engs):
         e.upload(p, v, m)
