@@ -57,6 +57,8 @@ SIGNATURES = {
     "bh_last_error": (C.c_char_p, [_ctx]),
     "bh_upload": (C.c_int, [_ctx, _dp, _dp, _dp, C.c_int64]),
     "bh_download": (C.c_int, [_ctx, _dp, _dp]),
+    "bh_initialize": (C.c_int, [_ctx, C.c_int64, C.c_uint64, C.c_int32] + [C.c_double] * 6),
+    "bh_download_masses": (C.c_int, [_ctx, _dp]),
     "bh_step": (C.c_int, [_ctx, C.c_int32]),
     "bh_sync": (C.c_int, [_ctx]),
     "bh_build_tree": (C.c_int, [_ctx]),

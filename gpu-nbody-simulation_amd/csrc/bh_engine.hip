@@ -16,6 +16,7 @@
 
 #include "bh_tree.hpp"
 #include "bh_walk_exact.hpp"
+#include "bh_init.hpp"
 #include "bh_walk_fast.h"
 
 using namespace bh;
@@ -186,10 +187,9 @@ int enqueue_build_t(bh_ctx *c)
 
     // 6. nodes (thread 0 writes the root when nothing is subdivided)
     const unsigned nbn = blocks_for(std::max<int64_t>(n, 1), kBlock);
-    if (EXACT) {
-        hipLaunchKernelGGL((nodes_kernel<true, true, Real2, Real>), dim3(nbn), dim3(kBlock), 0, st, c->keys_sorted,
-                           c->perm, c->cnt, pos, mass, c->box, c->terms, n, Dm, c->cfg.theta, c->internal_cap,
-                           c->gd, c->ld, c->qf, c->aux, c->self_node, c->cell_depth, c->ctr);
+    if constexpr (EXACT) {
+        hipLaunchKernelGGL(nodes_exact_kernel, dim3(nbn), dim3(kBlock), 0, st, c->keys_sorted, c->perm, c->cnt, pos,
+                           mass, c->box, n, Dm, c->internal_cap, c->gd, c->ld, c->self_node, c->cell_depth, c->ctr);
     } else {
         // one thread per subdivided cell; I <= (n-1)*Dm and <= internal_cap
         const int64_t span = std::max<int64_t>(1, std::min<int64_t>(c->internal_cap, std::max<int64_t>(n - 1, 0) * (int64_t)std::max(1, Dm)));
@@ -267,6 +267,8 @@ int check_overflow(bh_ctx *c)
 }  // namespace
 
 // ================================================================================================
+static int download_pairs(bh_ctx *c, const void *dev, double *host, int64_t count);
+
 extern "C" {
 
 int bh_abi_version(void) { return BHGPU_ABI_VERSION; }
@@ -414,9 +416,51 @@ static int download_pairs(bh_ctx *c, const void *dev, double *host, int64_t coun
     return BH_OK;
 }
 
+int bh_initialize(bh_ctx *c, int64_t n, uint64_t seed, int32_t kind, double lower_m, double higher_m,
+                  double lower_p, double higher_p, double lower_v, double higher_v)
+{
+    if (!c) return BH_ERR_ARG;
+    if (n < 0 || n > c->cfg.capacity)
+        return fail(c, BH_ERR_ARG, "Requested number of bodies exceeds N_BODIES.");
+    if (kind != 0 && kind != 1) return fail(c, BH_ERR_ARG, "bh_initialize: kind must be 0 (box) or 1 (plummer)");
+    BH_HIP(c, hipSetDevice(c->device));
+    if (n > 0) {
+        const unsigned g = blocks_for(n, kBlock);
+        if (c->exact)
+            hipLaunchKernelGGL((init_bodies_kernel<double2, double>), dim3(g), dim3(kBlock), 0, c->stream,
+                               (double2 *)c->pos, (double2 *)c->vel, (double *)c->mass, n, seed, kind, lower_m,
+                               higher_m, lower_p, higher_p, lower_v, higher_v);
+        else
+            hipLaunchKernelGGL((init_bodies_kernel<float2, float>), dim3(g), dim3(kBlock), 0, c->stream,
+                               (float2 *)c->pos, (float2 *)c->vel, (float *)c->mass, n, seed, kind, lower_m,
+                               higher_m, lower_p, higher_p, lower_v, higher_v);
+        BH_HIP(c, hipGetLastError());
+    }
+    BH_HIP(c, hipMemsetAsync(c->force, 0, std::max<int64_t>(n, 1) * 2 * (c->exact ? sizeof(double) : sizeof(float)), c->stream));
+    c->n = n;
+    c->partial_count = 0;
+    c->uploaded = true;
+    c->tree_valid = false;
+    c->steps_done = 0;
+    return BH_OK;
+}
+
+int bh_download_masses(bh_ctx *c, double *mass)
+{
+    if (!c || !mass) return fail(c, BH_ERR_ARG, "bh_download_masses: null array");
+    if (!c->uploaded) return fail(c, BH_ERR_STATE, "bh_download_masses before bh_upload/bh_initialize");
+    BH_HIP(c, hipSetDevice(c->device));
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+    return download_pairs(c, c->mass, mass, c->n);
+}
+
 int bh_sync(bh_ctx *c)
 {
     if (!c) return BH_ERR_ARG;
+    BH_HIP(c, hipSetDevice(c->device));
+    // also reports a tree that outgrew node_capacity during bh_step (the walk of such a step does
+    // nothing, so the state is the last good one)
+    if (c->tree_valid) return check_overflow(c);
     BH_HIP(c, hipStreamSynchronize(c->stream));
     return BH_OK;
 }
@@ -426,8 +470,10 @@ int bh_download(bh_ctx *c, double *pos, double *vel)
     if (!c || !pos) return fail(c, BH_ERR_ARG, "bh_download: null array");
     if (!c->uploaded) return fail(c, BH_ERR_STATE, "bh_download before bh_upload");
     BH_HIP(c, hipSetDevice(c->device));
+    int rc = c->tree_valid ? check_overflow(c) : BH_OK;
+    if (rc) return rc;
     BH_HIP(c, hipStreamSynchronize(c->stream));
-    int rc = download_pairs(c, c->pos, pos, 2 * c->n);
+    rc = download_pairs(c, c->pos, pos, 2 * c->n);
     if (rc) return rc;
     if (vel) rc = download_pairs(c, c->vel, vel, 2 * c->n);
     return rc;

@@ -300,17 +300,16 @@ __device__ __forceinline__ int64_t cell_end(const uint64_t *__restrict__ keys, i
     return lower_bound_prefix(keys, a + 1, b, sh, pfx + 1);
 }
 
-// ---- nodes: the owner of each subdivided cell writes its four children --------------------------
-// EXACT: NodeD/LinkD + self_node/cell_depth for the bottom-up pass.
-// !EXACT: one QuadF per cell, complete (COM from the fp64 prefix sums psum[0..n]) + NodeAux.
-// Thread 0 also writes the root when nothing is subdivided (n <= 1 or max_depth == 1).
-template <bool EXACT, bool COMPAT, typename Real2, typename Real>
-__global__ __launch_bounds__(kBlock) void nodes_kernel(
+// ---- exact-mode nodes kernel: the owner of each subdivided cell writes its four children --------
+// NodeD/LinkD + self_node/cell_depth for the bottom-up pass.  One thread per sorted neighbour pair;
+// a pair that starts a chain of nested cells handles them in turn (the fp32 kernel below runs one
+// thread per cell instead).  Thread 0 also writes the root when nothing is subdivided (n <= 1 or
+// max_depth == 1).
+__global__ __launch_bounds__(kBlock) void nodes_exact_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm,
-    const uint32_t *__restrict__ off, const Real2 *__restrict__ pos, const Real *__restrict__ mass,
-    const double *__restrict__ box, const d3 *__restrict__ psum, int64_t n, int Dm, double theta,
-    int64_t internal_cap, NodeD *__restrict__ gd, LinkD *__restrict__ ld, QuadF *__restrict__ qf,
-    NodeAux *__restrict__ aux, int32_t *__restrict__ self_node, int32_t *__restrict__ cell_depth,
+    const uint32_t *__restrict__ off, const double2 *__restrict__ pos, const double *__restrict__ mass,
+    const double *__restrict__ box, int64_t n, int Dm, int64_t internal_cap, NodeD *__restrict__ gd,
+    LinkD *__restrict__ ld, int32_t *__restrict__ self_node, int32_t *__restrict__ cell_depth,
     TreeCounters *ctr)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -324,7 +323,7 @@ __global__ __launch_bounds__(kBlock) void nodes_kernel(
         if (n >= 1 && Dm == 0) {
             for (int64_t j = 0; j < n; ++j) {
                 const uint32_t b = perm[j];
-                const double bm = (double)mass[b], bx = (double)pos[b].x, by = (double)pos[b].y;
+                const double bm = mass[b], bx = pos[b].x, by = pos[b].y;
                 cx = (m * cx + bm * bx) / (m + bm);
                 cy = (m * cy + bm * by) / (m + bm);
                 m += bm;
@@ -332,24 +331,12 @@ __global__ __launch_bounds__(kBlock) void nodes_kernel(
             occ = (n == 1) ? -(int)perm[0] - 2 : -1;
         } else if (n == 1) {
             const uint32_t b = perm[0];
-            m = (double)mass[b]; cx = (double)pos[b].x; cy = (double)pos[b].y;
+            m = mass[b]; cx = pos[b].x; cy = pos[b].y;
             occ = (int)b;
         }
         const double ex = box[1] - box[0], ey = box[3] - box[2];
-        const double size = (ex > ey) ? ex : ey;
-        if (EXACT) {
-            gd[0] = NodeD{cx, cy, m, size};
-            ld[0] = LinkD{-1, occ};
-        } else {
-            QuadF q;
-            for (int k = 0; k < 4; ++k) { q.xy[2 * k] = 0.f; q.xy[2 * k + 1] = 0.f; q.m[k] = 0.f; q.thr[k] = 0.f; q.child[k] = -1; }
-            q.xy[0] = (float)cx; q.xy[1] = (float)cy;
-            q.m[0] = (m > 1e-15) ? (float)m : 0.f;
-            if (n > 1 && !COMPAT) { q.child[0] = -2; q.thr[0] = INFINITY; }   // root itself is a bucket
-            qf[0] = q;
-            aux[0] = NodeAux{0, (int32_t)n};
-            for (int k = 1; k < 4; ++k) aux[k] = NodeAux{0, 0};
-        }
+        gd[0] = NodeD{cx, cy, m, (ex > ey) ? ex : ey};
+        ld[0] = LinkD{-1, occ};
         return;
     }
 
@@ -371,7 +358,6 @@ __global__ __launch_bounds__(kBlock) void nodes_kernel(
         const int c = (int)((key >> (2 * (Dm - 1 - l))) & 3);
         descend(c, (x0 + x1) / 2, (y0 + y1) / 2, x0, x1, y0, y1);
     }
-    const double inv_theta = 1.0 / theta;
 
     int64_t hi = n;
     for (int d = dlo; d <= dhi; ++d) {
@@ -386,33 +372,16 @@ __global__ __launch_bounds__(kBlock) void nodes_kernel(
         for (int c = 1; c < 4; ++c) b[c] = lower_bound_prefix(keys, b[c - 1], e, shc, (pfx << 2) | (uint64_t)c);
 
         const double mx = (x0 + x1) / 2.0, my = (y0 + y1) / 2.0;
-        const int32_t quad = EXACT ? 1 + 4 * (int32_t)r : 4 * ((int32_t)r + 1);   // id of child 0
+        const int32_t quad = 1 + 4 * (int32_t)r;     // id of child 0
 
-        if (d == 0) {                                  // root record
+        if (d == 0) {                                  // root record (mass/COM come bottom-up)
             const double ex = x1 - x0, ey = y1 - y0;
-            const double size = (ex > ey) ? ex : ey;
-            if (EXACT) {
-                gd[0].size = size;
-                ld[0] = LinkD{quad, -1};
-                self_node[0] = 0;
-                cell_depth[0] = 0;
-            } else {
-                QuadF q;
-                for (int k = 0; k < 4; ++k) { q.xy[2 * k] = 0.f; q.xy[2 * k + 1] = 0.f; q.m[k] = 0.f; q.thr[k] = 0.f; q.child[k] = -1; }
-                const d3 t = psum[n];
-                if (t.a > 1e-15) {
-                    q.m[0] = (float)t.a; q.xy[0] = (float)(t.b / t.a); q.xy[1] = (float)(t.c / t.a);
-                    const double s = size * inv_theta;
-                    q.thr[0] = (float)(s * s);
-                    q.child[0] = (int32_t)r + 1;
-                }
-                qf[0] = q;
-                aux[0] = NodeAux{0, (int32_t)n};
-                for (int k = 1; k < 4; ++k) aux[k] = NodeAux{0, 0};
-            }
+            gd[0].size = (ex > ey) ? ex : ey;
+            ld[0] = LinkD{quad, -1};
+            self_node[0] = 0;
+            cell_depth[0] = 0;
         }
 
-        QuadF q;
         for (int c = 0; c < 4; ++c) {
             const double cx0 = (c & 1) ? mx : x0, cx1 = (c & 1) ? x1 : mx;
             const double cy0 = (c & 2) ? my : y0, cy1 = (c & 2) ? y1 : my;
@@ -422,61 +391,34 @@ __global__ __launch_bounds__(kBlock) void nodes_kernel(
             const int32_t node = quad + c;
             double m = 0.0, cx = 0.0, cy = 0.0;
             int32_t child = -1, occ = -1;
-            float thr = -1.0f;
             if (nc == 0) {
                 // empty leaf: blank child of project.cu:422-428
             } else if (d + 1 == Dm) {
-                // depth-cap cell, project.cu:360-382
-                if (EXACT) {                           // running mean in body order
-                    for (int64_t j = bc; j < bc + nc; ++j) {
-                        const uint32_t bi = perm[j];
-                        const double bm = (double)mass[bi], bx = (double)pos[bi].x, by = (double)pos[bi].y;
-                        cx = (m * cx + bm * bx) / (m + bm);
-                        cy = (m * cy + bm * by) / (m + bm);
-                        m += bm;
-                    }
-                    occ = (nc == 1) ? (-(int32_t)perm[bc] - 2) : -1;
-                } else if (nc == 1) {
-                    const uint32_t bi = perm[bc];
-                    cx = (double)pos[bi].x; cy = (double)pos[bi].y; m = (double)mass[bi];
-                } else {
-                    const d3 lo_s = psum[bc], hi_s = psum[bc + nc];
-                    m = hi_s.a - lo_s.a;
-                    cx = (hi_s.b - lo_s.b) / m; cy = (hi_s.c - lo_s.c) / m;
-                    if (!COMPAT) { thr = INFINITY; child = -node - 2; }    // bucket leaf
+                // depth-cap cell, project.cu:360-382: running mean in body order
+                for (int64_t j = bc; j < bc + nc; ++j) {
+                    const uint32_t bi = perm[j];
+                    const double bm = mass[bi], bx = pos[bi].x, by = pos[bi].y;
+                    cx = (m * cx + bm * bx) / (m + bm);
+                    cy = (m * cy + bm * by) / (m + bm);
+                    m += bm;
                 }
+                occ = (nc == 1) ? (-(int32_t)perm[bc] - 2) : -1;
             } else if (nc == 1) {
                 // single body in an undivided cell, project.cu:398-406
                 const uint32_t bi = perm[bc];
-                m = (double)mass[bi]; cx = (double)pos[bi].x; cy = (double)pos[bi].y;
+                m = mass[bi]; cx = pos[bi].x; cy = pos[bi].y;
                 occ = (int32_t)bi;
             } else {
                 // subdivided cell: its rank follows from its first body and depth
                 const int Lpc = (bc == 0) ? -1 : shared_levels(keys[bc - 1], keys[bc], Dm);
                 const uint32_t rc = off[bc] + (uint32_t)((d + 1) - (Lpc + 1));
-                if (EXACT) {
-                    child = 1 + 4 * (int32_t)rc;
-                    self_node[rc] = node;
-                    cell_depth[rc] = d + 1;
-                } else {
-                    child = (int32_t)rc + 1;
-                    const d3 lo_s = psum[bc], hi_s = psum[bc + nc];
-                    m = hi_s.a - lo_s.a;
-                    cx = (hi_s.b - lo_s.b) / m; cy = (hi_s.c - lo_s.c) / m;
-                    const double s = size * inv_theta;
-                    thr = (float)(s * s);
-                }
+                child = 1 + 4 * (int32_t)rc;
+                self_node[rc] = node;
+                cell_depth[rc] = d + 1;
             }
-            if (EXACT) {
-                gd[node] = NodeD{cx, cy, m, size};
-                ld[node] = LinkD{child, occ};
-            } else {
-                if (!(m > 1e-15)) { m = 0.0; cx = 0.0; cy = 0.0; child = -1; thr = -1.0f; }   // project.cu:617
-                q.xy[2 * c] = (float)cx; q.xy[2 * c + 1] = (float)cy; q.m[c] = (float)m; q.thr[c] = thr; q.child[c] = child;
-                aux[node] = NodeAux{(int32_t)bc, (int32_t)nc};
-            }
+            gd[node] = NodeD{cx, cy, m, size};
+            ld[node] = LinkD{child, occ};
         }
-        if (!EXACT) qf[r + 1] = q;
         // descend into the child that holds body i (the next cell of this owner's chain)
         if (d < dhi) {
             const int c = (int)((key >> (2 * (Dm - 1 - d))) & 3);
@@ -493,13 +435,13 @@ __global__ __launch_bounds__(kBlock) void nodes_kernel(
 //   * no fp64 box tracking: fp32 only needs the MAC threshold (size/theta)^2, and the cell size at
 //     depth d is root_size * 2^-d to far better than fp32 resolution;
 //   * single bodies come from the sorted copies (neighbouring addresses), not through perm;
-//   * fields are stored as they are produced, so the kernel stays under 64 VGPRs (8 waves/SIMD;
-//     the generic kernel needs 104 and ran at 4).
+//   * one thread per CELL and coalesced LDS-staged stores (see the kernel); LDS (36 KB per
+//     workgroup: key window + staging) bounds residency at 4 workgroups per CU.
 constexpr int kKeyHalo = 768;
 constexpr int kKeyWin = kBlock + 1 + kKeyHalo;
 
 template <bool COMPAT>
-__global__ __launch_bounds__(kBlock, 8) void nodes_fast_kernel(
+__global__ __launch_bounds__(kBlock, 4) void nodes_fast_kernel(
     const uint64_t *__restrict__ keys, const uint64_t *__restrict__ coarse,
     const uint32_t *__restrict__ off, const uint32_t *__restrict__ cell_first,
     const float2 *__restrict__ spos,

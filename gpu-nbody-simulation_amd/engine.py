@@ -120,6 +120,21 @@ class BarnesHutEngine:
         self._check(self._lib.bh_download(self._h, _dptr(pos), _dptr(vel)))
         return pos, vel
 
+    def initialize(self, n: int, seed: int = 0, kind: str = "box", lower_m=1e-1, higher_m=5e-1,
+                   lower_p=-1e-1, higher_p=1e-1, lower_v=-1e-4, higher_v=1e-4) -> None:
+        """On-device initial conditions (initializeGpu, project.cu:304-341; defaults = its
+        constants, project.cu:30-35).  kind "plummer": scale lower_p, truncation higher_p, equal
+        masses higher_m, zero velocities."""
+        k = {"box": 0, "plummer": 1}[kind]
+        self._check(self._lib.bh_initialize(self._h, n, seed, k, lower_m, higher_m, lower_p, higher_p,
+                                            lower_v, higher_v))
+        self.n = n
+
+    def masses(self) -> np.ndarray:
+        m = np.empty(self.n)
+        self._check(self._lib.bh_download_masses(self._h, _dptr(m)))
+        return m
+
     # -- hot path ---------------------------------------------------------------------------
     def step(self, nsteps: int = 1) -> None:
         self._check(self._lib.bh_step(self._h, nsteps))

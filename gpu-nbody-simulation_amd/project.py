@@ -52,14 +52,34 @@ def initializeCpu(n_bodies: int, seed: int = 0, save_to_file: bool = False):
     return masses, positions, velocities
 
 
+def initializeGpu(n_bodies: int, seed: int = 0, precision: Precision = Precision.F64_EXACT,
+                  save_to_file: bool = False, device: int = 0):
+    """initializeGpu (project.cu:304-341): bodies generated on the device with the reference's
+    ranges (project.cu:30-35), reproducible for a given seed (the reference seeds cuRAND from
+    time(NULL), project.cu:323).  save_to_file writes the three init files as initializeCpu's
+    save_to_file branch does (project.cu:298-302)."""
+    with BarnesHutEngine(BhConfig(capacity=max(n_bodies, 1), precision=precision, device=device)) as eng:
+        eng.initialize(n_bodies, seed, "box", LOWER_M, HIGHER_M, LOWER_P, HIGHER_P, LOWER_V, HIGHER_V)
+        positions, velocities = eng.download()
+        masses = eng.masses()
+    if save_to_file:
+        from .textio import save_init_files
+        save_init_files(masses, positions, velocities)
+    return masses, positions, velocities
+
+
 def runSimulationGpu(masses, positions, velocities, n_simulations: int, *, n_threads: int = 0,
                      theta: float = THETA, g: float = G, delta_t: float = DELTA_T,
                      max_depth: int = QUADTREE_MAX_DEPTH, precision: Precision = Precision.F64_EXACT,
-                     reference_compat: bool = True, out_dir: str = ".", device: int = 0):
+                     reference_compat: bool = True, out_dir: str = ".", device: int = 0,
+                     positions_file: str | None = None):
     """Returns (final_positions, final_velocities, gpu_parallel_duration_us).
 
     positions is NOT modified in place (the reference updates its by-reference argument,
-    project.cu:918, 1010; the caller gets the same values as the first return value)."""
+    project.cu:918, 1010; the caller gets the same values as the first return value).
+    positions_file: also write the trajectory as runSimulationCpu does into positions_cpu.txt
+    (savePositions, project.cu:855-863, 876, 909: `t i x y ` per body, before the first step and
+    after every step); this downloads the positions every step."""
     n = len(masses)
     # both files are opened (truncated) up front, as the reference's ofstreams are (project.cu:928-929)
     init_path = os.path.join(out_dir, "quadtree_init_gpu.txt")
@@ -72,13 +92,25 @@ def runSimulationGpu(masses, positions, velocities, n_simulations: int, *, n_thr
                                   precision=precision, reference_compat=reference_compat,
                                   device=device, n_threads=n_threads)) as eng:
         eng.upload(positions, velocities, masses)
+        traj = None
+        absolute_t = 0.0
+        if positions_file is not None:
+            traj = open(os.path.join(out_dir, positions_file) if not os.path.isabs(positions_file) else positions_file, "w")
+            _write_frame(traj, absolute_t, np.asarray(positions, dtype=np.float64))
 
         def advance(k):
-            nonlocal gpu_parallel_us
+            nonlocal gpu_parallel_us, absolute_t
             if k <= 0:
                 return
-            eng.step(k)
-            gpu_parallel_us += eng.stats().last_step_ms * k * 1e3
+            if traj is None:
+                eng.step(k)
+                gpu_parallel_us += eng.stats().last_step_ms * k * 1e3
+                return
+            for _ in range(k):
+                eng.step(1)
+                gpu_parallel_us += eng.stats().last_step_ms * 1e3
+                absolute_t += delta_t
+                _write_frame(traj, absolute_t, eng.download()[0])
 
         step = 0
         while step < n_simulations:
@@ -97,7 +129,14 @@ def runSimulationGpu(masses, positions, velocities, n_simulations: int, *, n_thr
                 advance(k)
                 step += k
         pos, vel = eng.download()
+        if traj is not None:
+            traj.close()
     return pos, vel, gpu_parallel_us
+
+
+def _write_frame(f, t: float, pos) -> None:
+    """One savePositions call (project.cu:855-863): std::to_string formatting is "%f"."""
+    f.write("".join("%f %d %f %f \n" % (t, i, x, y) for i, (x, y) in enumerate(pos)))
 
 
 def _parse(argv):
@@ -108,9 +147,12 @@ def _parse(argv):
     ap.add_argument("--n-bodies", type=int)
     ap.add_argument("--n-threads", type=int)
     ap.add_argument("--n-simulations", type=int)
-    ap.add_argument("--init", choices=["auto", "files", "random"], default="auto",
+    ap.add_argument("--init", choices=["auto", "files", "random", "gpu"], default="auto",
                     help="files: loadSimulationDataFromText from the CWD; random: initializeCpu; "
-                         "auto: files when masses_init.txt exists, else random")
+                         "gpu: initializeGpu (on-device generator); auto: files when masses_init.txt "
+                         "exists, else gpu -- the reference as shipped calls initializeGpu")
+    ap.add_argument("--positions-file", default=None, help="also write the trajectory (savePositions format)")
+    ap.add_argument("--save-init", action="store_true", help="write the three init files after initialisation")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--max-depth", type=int, default=QUADTREE_MAX_DEPTH)
@@ -141,15 +183,19 @@ def main(argv=None) -> int:
     if use_files:
         masses, positions, velocities = loadSimulationDataFromText(
             "masses_init.txt", "positions_init.txt", "velocities_init.txt", n, N_BODIES=n)
+    elif a.init == "random":
+        masses, positions, velocities = initializeCpu(n, seed=a.seed, save_to_file=a.save_init)
     else:
-        masses, positions, velocities = initializeCpu(n, seed=a.seed)
+        masses, positions, velocities = initializeGpu(
+            n, seed=a.seed, precision=Precision.F64_EXACT if a.precision == "f64" else Precision.F32,
+            save_to_file=a.save_init)
 
     start = time.perf_counter()
     _, _, gpu_parallel_us = runSimulationGpu(
         masses, positions, velocities, mac["N_SIMULATIONS"], n_threads=mac["N_THREADS"],
         theta=a.theta, max_depth=a.max_depth,
         precision=Precision.F64_EXACT if a.precision == "f64" else Precision.F32,
-        reference_compat=not a.no_compat)
+        reference_compat=not a.no_compat, positions_file=a.positions_file)
     duration_ms = int((time.perf_counter() - start) * 1e3)
 
     # project.cu:1090-1102, blank lines included

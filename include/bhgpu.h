@@ -120,6 +120,17 @@ int bh_abi_version(void);
 int bh_upload(bh_ctx *ctx, const double *pos, const double *vel, const double *mass, int64_t n);
 int bh_download(bh_ctx *ctx, double *pos, double *vel);
 
+/* bh_initialize replaces initializeGpu (project.cu:304-341): bodies are generated on the device
+ * by a counter-based generator, reproducible for a given (seed, n).  kind 0 = the reference's box
+ * distribution: masses in [lower_m, higher_m], positions in [lower_p, higher_p]^2, velocities in
+ * [lower_v, higher_v]^2, each range log-uniform when both bounds are positive and linear otherwise
+ * (generateRandomGpu, project.cu:84-97).  kind 1 = projected Plummer sphere (BASELINE config 3):
+ * scale lower_p, truncation radius higher_p, equal masses higher_m, zero velocities.
+ * bh_download_masses returns the masses (the caller supplied them in bh_upload otherwise). */
+int bh_initialize(bh_ctx *ctx, int64_t n, uint64_t seed, int32_t kind, double lower_m, double higher_m,
+                  double lower_p, double higher_p, double lower_v, double higher_v);
+int bh_download_masses(bh_ctx *ctx, double *mass);
+
 /* --- the hot path -----------------------------------------------------------------------
  * bh_step: nsteps x { buildTree (project.cu:575-591), computeForcesGpu (:679-793),
  * updateAccVelPos (:819-836) }, i.e. the body of the step loop project.cu:955-1011, with

@@ -1,0 +1,53 @@
+"""SURVEY 8(f) rows that need no GPU: the nvcc stand-in writes a launcher for the reference's own
+command line, and the results parser reads the reference's results format."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NVCC = os.path.join(ROOT, "gpu-nbody-simulation_amd", "compat", "nvcc")
+
+
+def test_nvcc_standin_writes_the_project_launcher(tmp_path):
+    # first_scaling_script.sh:30, verbatim shape
+    subprocess.check_call([sys.executable, NVCC, "-DN_BODIES=40000", "-DN_THREADS=1024", "-DN_SIMULATIONS=10",
+                           "-o", "project", "project.cu"], cwd=tmp_path)
+    launcher = tmp_path / "project"
+    assert os.access(launcher, os.X_OK)
+    text = launcher.read_text()
+    assert "gpu_nbody_simulation_amd.project -DN_BODIES=40000 -DN_THREADS=1024 -DN_SIMULATIONS=10" in text
+    assert f'PYTHONPATH="{ROOT}' in text
+
+
+def test_nvcc_standin_refuses_other_inputs(tmp_path):
+    r = subprocess.run([sys.executable, NVCC, "-o", "x", "other.cu"], cwd=tmp_path, capture_output=True)
+    assert r.returncode != 0 and b"only `project.cu`" in r.stderr
+    r = subprocess.run([sys.executable, NVCC, "-DFOO=1", "-o", "x", "project.cu"], cwd=tmp_path, capture_output=True)
+    assert r.returncode != 0
+
+
+def test_results_parser_reads_the_references_format(tmp_path):
+    from gpu_nbody_simulation_amd import scaling
+    f = tmp_path / "first_scaling_results.txt"
+    # header + records as first_scaling_script.sh:15,36 writes them ($runtime spans several lines)
+    f.write_text("n_bodies, n_threads, n_simulations, runtime\n"
+                 "40000, 1, 10, \n\n\n\nGPU total computation took 5000 milliseconds.\n\n\n"
+                 "GPU parallel computation took 4000000 microseconds.\n"
+                 "40000, 1024, 10, \n\nGPU total computation took 1200 milliseconds.\n\n"
+                 "GPU parallel computation took 8000 microseconds.\n"
+                 "40000, 1024, 10, \n\nGPU total computation took 1100 milliseconds.\n\n"
+                 "GPU parallel computation took 6000 microseconds.\n")
+    recs = scaling.parse_results(str(f))
+    assert [r["parallel_us"] for r in recs] == [4000000, 8000, 6000]
+    rows = scaling.summarise(recs)
+    assert len(rows) == 2 and rows[1]["runs"] == 2 and rows[1]["parallel_us"] == 7000
+    assert abs(rows[1]["speedup_parallel"] - 4000000 / 7000) < 1e-9
+    assert abs(rows[1]["body_steps_per_s"] - 40000 * 10 / 7e-3) < 1e-3
+
+
+def test_project_argument_parsing():
+    from gpu_nbody_simulation_amd import project
+    a, mac = project._parse(["-DN_BODIES=1000 * 40", "-DN_THREADS=32", "-o", "project", "project.cu"])
+    assert mac == {"N_BODIES": 40000, "N_THREADS": 32, "N_SIMULATIONS": 10}        # project.cu:1-11
+    a, mac = project._parse([])
+    assert mac == {"N_BODIES": 40000, "N_THREADS": 1024, "N_SIMULATIONS": 10}

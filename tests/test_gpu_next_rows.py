@@ -1,0 +1,103 @@
+"""SURVEY 8(f) rows on the GPU: on-device initialisers, trajectory writer, scaling-script shim."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bh_oracle as O  # noqa: E402
+import gpu_nbody_simulation_amd as G  # noqa: E402
+from gpu_nbody_simulation_amd import project, scaling, textio  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.mark.parametrize("precision", [G.Precision.F64_EXACT, G.Precision.F32])
+def test_device_initialiser_box_distribution(precision):
+    """initializeGpu (project.cu:304-341) with the reference's ranges (project.cu:30-35): masses
+    log-uniform on [0.1, 0.5] (both bounds positive, project.cu:86-89), vectors linear."""
+    n = 200000
+    with G.BarnesHutEngine(G.BhConfig(capacity=n, precision=precision)) as e:
+        e.initialize(n, seed=7)
+        p, v = e.download()
+        m = e.masses()
+        e.initialize(n, seed=7)
+        p2, v2 = e.download()
+        e.initialize(n, seed=8)
+        p3, _ = e.download()
+    assert np.array_equal(p, p2) and np.array_equal(v, v2) and not np.array_equal(p, p3)
+    assert 0.1 <= m.min() and m.max() <= 0.5 and -0.1 <= p.min() and p.max() <= 0.1 and np.abs(v).max() <= 1e-4
+    lm = np.log10(m)
+    assert abs(lm.mean() - (np.log10(0.1) + np.log10(0.5)) / 2) < 2e-3          # log-uniform
+    assert abs(p.mean()) < 1e-3 and abs(p.std() - 0.2 / np.sqrt(12)) < 5e-4      # uniform
+    assert abs(np.corrcoef(p[:, 0], p[:, 1])[0, 1]) < 0.01                       # independent streams
+    assert len(np.unique(p[:, 0])) > 0.99 * n or precision == G.Precision.F32
+
+
+def test_device_initialiser_plummer():
+    n = 200000
+    with G.BarnesHutEngine(G.BhConfig(capacity=n, precision=G.Precision.F32, max_depth=21, reference_compat=False)) as e:
+        e.initialize(n, seed=1, kind="plummer", higher_m=1e-8 / n, lower_p=0.02, higher_p=0.2)
+        p, v = e.download()
+        m = e.masses()
+        e.step(2)
+        p2, _ = e.download()
+    r = np.hypot(p[:, 0], p[:, 1])
+    assert r.max() <= 0.2 * (1 + 1e-6) and not v.any() and np.allclose(m, 1e-8 / n, rtol=1e-6)
+    assert 0.49 < (r < 0.02).mean() < 0.53
+    assert np.isfinite(p2).all()
+
+
+def test_initializeGpu_and_saved_files_round_trip(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    m, p, v = project.initializeGpu(1000, seed=3, save_to_file=True)
+    m2, p2, v2 = textio.loadSimulationDataFromText("masses_init.txt", "positions_init.txt",
+                                                   "velocities_init.txt", 1000, verbose=False)
+    assert np.allclose(m2, m, rtol=1e-5) and np.allclose(p2, p, rtol=1e-5, atol=1e-12)   # 6 significant digits
+
+
+def test_trajectory_file_matches_the_oracle(tmp_path, init1024):
+    """positions file as runSimulationCpu writes it (savePositions, project.cu:855-863, 876, 909)."""
+    m, p, v = init1024
+    project.runSimulationGpu(m, p, v, 3, out_dir=str(tmp_path), positions_file="positions_gpu.txt")
+    lines = (tmp_path / "positions_gpu.txt").read_text().splitlines()
+    assert len(lines) == 4 * 1024
+    want = []
+    pp, vv = p.copy(), v.copy()
+    for s in range(4):
+        want += ["%f %d %f %f " % (float(s), i, x, y) for i, (x, y) in enumerate(pp)]
+        pp, vv = O.run(pp, vv, m, 1, max_depth=10)
+    assert lines == want
+
+
+def test_reference_scaling_script_lines_run_unchanged(tmp_path):
+    """The two lines of first_scaling_script.sh:30,33 with the stand-in first on PATH."""
+    for f in ("masses", "positions", "velocities"):
+        shutil.copy(os.path.join(GOLD, "init1024", f"{f}_init.txt"), tmp_path / f"{f}_init.txt")
+    env = dict(os.environ, PATH=os.path.join(ROOT, "gpu-nbody-simulation_amd", "compat") + os.pathsep + os.environ["PATH"])
+    script = ('set -e\n'
+              'nvcc -DN_BODIES=1024 -DN_THREADS=64 -DN_SIMULATIONS=5 -o project project.cu\n'
+              'runtime=$(./project)\n'
+              'echo "1024, 64, 5, $runtime" >> results.txt\n')
+    subprocess.check_call(["bash", "-c", script], cwd=tmp_path, env=env)
+    recs = scaling.parse_results(str(tmp_path / "results.txt"))
+    assert len(recs) == 1 and recs[0]["n_bodies"] == 1024 and recs[0]["parallel_us"] > 0
+    assert os.path.getsize(tmp_path / "quadtree_init_gpu.txt") > 0
+
+
+def test_overflow_is_reported_by_sync_after_step():
+    r = np.random.default_rng(0)
+    n = 4096
+    m, p, v = 10.0 ** r.uniform(-2, 1, n), r.uniform(-0.1, 0.1, (n, 2)), r.uniform(-1e-4, 1e-4, (n, 2))
+    with G.BarnesHutEngine(G.BhConfig(capacity=n, node_capacity=101, precision=G.Precision.F32, max_depth=16)) as e:
+        e.upload(p, v, m)
+        e.step(1)
+        with pytest.raises(G.BhError) as ei:
+            e.sync()
+        assert ei.value.code == -4
