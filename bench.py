@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--lds-stack", action="store_true", help="A/B: LDS traversal stack variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the second distribution")
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="bodies walked by the CPU baseline (0 = all, i.e. one full step)")
     return ap.parse_args()
@@ -75,8 +76,18 @@ def cpu_baseline(mass, pos, theta, sample):
                     break
     except OSError:
         pass
+    # also the reference's own depth cap (QUADTREE_MAX_DEPTH = 10, project.cu:61),
+    # which is degenerate at this size (a saturated tree, ~4 bodies per leaf cell, aggregated)
+    t3 = time.perf_counter()
+    tree10 = O.build_tree(pos, mass, 10)
+    t4 = time.perf_counter()
+    s10 = max(1, sample // 8)
+    O.compute_forces(tree10, pos, mass, theta=theta, compat_self_skip=True, lo=0, hi=s10)
+    t5 = time.perf_counter()
+    cap10 = n / ((t4 - t3) + (t5 - t4) * n / s10)
     return {
         "value": n / est_step, "unit": "body-steps/s", "cores": 1, "kind": "port",
+        "depth_cap_10_body_steps_per_s": cap10,
         "sample": (f"one step at N={n}: full tree build ({build_s:.2f} s) + theta-walk of {sample} bodies "
                    f"({walk_s:.2f} s)" + ("" if sample == n else ", walk scaled to N")),
         "force_update_only_body_steps_per_s": sample / walk_s,
@@ -189,6 +200,22 @@ def main():
             "build_ms": st.build_ms, "walk_ms": st.walk_ms, "n_nodes": ss.n_nodes,
             "roofline": roof,
         }
+        if world == 1 and not a.no_secondary:
+            # the uniform distribution next to the Plummer one (same N, theta, steps)
+            other = "uniform" if a.init == "plummer" else "plummer"
+            m2, p2, v2 = IC.make(other, n, a.seed, quasi_static=True)
+            with G.BarnesHutEngine(cfg) as e2:
+                e2.upload(p2, v2, m2)
+                e2.step(a.warmup)
+                e2.sync()
+                t0 = time.perf_counter()
+                e2.step(a.steps)
+                e2.sync()
+                dt2 = time.perf_counter() - t0
+                s2 = e2.stats()
+            out["secondary"] = {"workload": f"{other}_N{n}_theta{a.theta}", "value": n * a.steps / dt2,
+                                "unit": "body-steps/s", "ms_per_step": dt2 / a.steps * 1e3,
+                                "build_ms": s2.build_ms, "walk_ms": s2.walk_ms}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(mass, pos, a.theta, a.cpu_sample)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

@@ -22,13 +22,9 @@
 //               ComputeMass does (project.cu:473-502).  fp32 mode: from fp64 prefix sums.
 //
 // Launch count matters as much as kernel quality here: on MI355X every launch costs ~6 us (4.7 us
-// minimum kernel duration + boundary), so the pipeline is fused to 16 launches per step at
-// max_depth 21 (it was 40): bounds_final | keys+hist | 5 x (scatter, hist) | prep | scan_top2 |
-// scan_apply2 | nodes | walk.
-//
-// Depth convention: d = 0 is the root ("file depth", TraverseTreeToFile's first column);
-// Dm = max_depth-1 is the depth of the cap cells.  Everything here is compiled with
-// -ffp-contract=off.
+// minimum kernel duration + boundary).  Per step at max_depth 21: bounds_final | keys |
+// 5 x (hist, rowscan, scatter) | prep | scan_top2 | scan_apply2 | nodes | walk = 22 launches
+// (it was 40).
 #pragma once
 
 #include "bh_prims.hpp"

@@ -9,18 +9,21 @@
 //   * the four children of a subdivided cell are one 80-byte structure-of-arrays record and are
 //     evaluated together: one memory round trip per opened cell instead of one per node, and that
 //     round trip is overlapped with the evaluation of the previous quad (see the kernel);
-//   * a stack entry is {first child, 64-bit lane mask of the bodies that opened the parent}.  The
+//   * a stack entry is {child quad, 64-bit lane mask of the bodies that opened the parent}.  The
 //     default stack lives in three VGPRs addressed by lane (v_writelane/v_readlane): entry k sits
 //     in lane k, so push/pop are single VALU instructions with no LDS round trip.  The LDS
 //     variant (BH_FLAG_LDS_STACK, and automatically for max_depth > 21 where 64 entries do not
 //     suffice) keeps the same entries in LDS; DESIGN.md quotes the measured difference.
 //   * MAC per body exactly as the reference's (size/dist < theta, evaluated per lane), in the
-//     algebraically equal form d2 > (size/theta)^2 with the right side precomputed per node.
+//     algebraically equal form d2 > (size/theta)^2 with the right side precomputed per node; the
+//     same compare doubles as the self test for leaves (thr = 0) -- see eval().
 //   * force per accepted node: G*M*d/(|d|^3) through v_rsq_f32; the reference's 1e-15 offset on
 //     dist (project.cu:634) is below fp32 resolution and omitted; a node at distance exactly 0
 //     (the body itself, or an exactly coincident body) contributes nothing.
 //   * epilogue: a = G*sum, v += a*dt, p += v*dt written back in caller order (scatter through
-//     perm), or into the sorted arrays for the multi-GPU exchange.
+//     perm), or into the sorted arrays for the multi-GPU exchange; plus the per-workgroup min/max of
+//     the new positions for the next step's root box.
+//   * BH_WALK_PIPE / BH_WALK_XCD select measured-and-rejected loop variants.
 #include "bh_prims.hpp"
 #include "bh_nodes.hpp"
 #include "bh_bounds.hpp"
