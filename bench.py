@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--lds-stack", action="store_true", help="A/B: LDS traversal stack variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second distribution")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="take the multi-GPU exchange path (step_local, all_gather, scatter) even on one rank")
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="bodies walked by the CPU baseline (0 = all, i.e. one full step)")
     return ap.parse_args()
@@ -107,6 +109,8 @@ def main():
     from gpu_nbody_simulation_amd.engine import FLAG_LDS_STACK, FLAG_WALK_STATS
 
     rank, local, world = init_process_group_from_env("nccl")
+    if a.force_sharded and world == 1 and not dist.is_initialized() and "RANK" in os.environ:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
     if world != a.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
@@ -123,10 +127,10 @@ def main():
     cfg = G.BhConfig(capacity=n, theta=a.theta, max_depth=a.max_depth, precision=G.Precision.F32,
                      reference_compat=False, device=local, flags=flags)
     eng = G.BarnesHutEngine(cfg)
-    if world > 1:
+    if world > 1 or a.force_sharded:
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.upload(pos, vel, mass)                       # bodies resident in HBM from here on
-    stepper = ShardedStepper(eng, rank, world, n, dev)
+    stepper = ShardedStepper(eng, rank, world, n, dev, force_exchange=a.force_sharded)
 
     def sync_all():
         eng.sync()
@@ -138,7 +142,7 @@ def main():
         stepper.step()
     sync_all()
     t0 = time.perf_counter()
-    if world == 1:
+    if world == 1 and not a.force_sharded:
         eng.step(a.steps)                            # K steps enqueued back to back on one stream
     else:
         for _ in range(a.steps):
@@ -151,7 +155,7 @@ def main():
         elapsed = float(t.item())
 
     st = eng.stats()                                 # HIP events recorded inside the timed region
-    walk_ms = st.walk_ms if world == 1 else None
+    walk_ms = st.walk_ms if (world == 1 and not a.force_sharded) else None
 
     # ---- untimed: counters of one walk on the final state (second engine, stats variant) --------
     pf, vf = eng.download()
@@ -222,7 +226,7 @@ def main():
         else:
             out["cpu_baseline"] = None
     eng.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -50,15 +50,19 @@ def init_process_group_from_env(backend: str | None = None):
 class ShardedStepper:
     """step() = local build + walk of the owned sorted range, all_gather, scatter to caller order."""
 
-    def __init__(self, engine, rank: int, world: int, n: int, device: torch.device | None = None):
+    def __init__(self, engine, rank: int, world: int, n: int, device: torch.device | None = None,
+                 force_exchange: bool = False):
+        """force_exchange: take the exchange path even for world == 1 (rehearses the collective on a
+        single rank; used by the tests and `bench.py --force-sharded`)."""
         self.eng, self.rank, self.world, self.n = engine, rank, world, n
+        self.exchange = world > 1 or force_exchange
         per = (n + world - 1) // world
         self.chunk = (per + 255) // 256 * 256       # workgroup-aligned, as bh_owned_range computes it
         engine.set_owned_fraction(rank, world)
         lo, hi = engine.owned_range()
         assert (lo, hi) == (min(n, self.chunk * rank), min(n, self.chunk * (rank + 1)))
         self.lo, self.hi = lo, hi
-        if world > 1:
+        if self.exchange:
             sp, sv = engine.device_sorted()
             nel = 2 * self.chunk * world        # float2 per body; buffers hold chunk*world slots
             if isinstance(sp, torch.Tensor):    # stand-in engines hand tensors over directly
@@ -68,12 +72,17 @@ class ShardedStepper:
                 self.svel = wrap_device_f32(sv, nel, device)
 
     def step(self) -> None:
-        if self.world == 1:
+        if not self.exchange:
             self.eng.step(1)
             return
         self.eng.step_local()
         c2 = 2 * self.chunk
         for buf in (self.spos, self.svel):
-            mine = buf[self.rank * c2:(self.rank + 1) * c2]
-            dist.all_gather_into_tensor(buf[: self.world * c2], mine)      # in place
+            # fixed-size block per rank; the send block is a copy so the collective never aliases
+            # its own output (2 MB per rank at N = 1M on 8 ranks)
+            mine = buf[self.rank * c2:(self.rank + 1) * c2].clone()
+            if dist.is_initialized():
+                dist.all_gather_into_tensor(buf[: self.world * c2], mine)
+            else:
+                assert self.world == 1
         self.eng.scatter_sorted()

@@ -49,3 +49,25 @@ def test_emulated_ranks_equal_single_context(n, world):
         assert np.array_equal(pe, pr) and np.array_equal(ve, vr)
         e.close()
     ref.close()
+
+
+def test_bench_exchange_path_on_real_rccl_single_rank(tmp_path):
+    """bench.py through torch.distributed.run with ONE rank and --force-sharded: the same
+    step_local -> all_gather_into_tensor (backend nccl = RCCL) -> scatter_sorted path the driver
+    runs on 2/4/8 GPUs, and it must give the same bodies/s order of magnitude and a sane tree."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1",
+           "--steps", "3", "--warmup", "1", "--n-bodies", "65536", "--max-depth", "16", "--force-sharded",
+           "--no-cpu-baseline", "--no-secondary"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 1e6 and 1 + 4 * 40000 < d["n_nodes"] < 4 * 65536
+    assert 150 < d["interactions_per_body"] < 400
