@@ -57,6 +57,9 @@ struct bh_ctx {
     uint64_t *keys_sorted = nullptr;
     uint32_t *perm = nullptr;
     uint32_t *radix_counts = nullptr, *bsum_sort = nullptr, *bsum_u32 = nullptr, *cnt = nullptr;
+    uint32_t *os_ghist = nullptr, *os_status = nullptr, *os_counter = nullptr, *os_err = nullptr;   // onesweep
+    int64_t os_status_words = 0;
+    bool sort_onesweep = false;          // BH_SORT_ONESWEEP=1 selects the look-back sort (measured slower, A/B)
     uint64_t *coarse = nullptr;          // fp32: every 256th sorted key
     uint32_t *cell_first = nullptr;      // fp32: rank of a subdivided cell -> its first sorted body
     d3 *terms = nullptr, *bsum_d3 = nullptr;
@@ -156,6 +159,21 @@ int enqueue_build_t(bh_ctx *c)
                            c->keys[0], c->vals[0], n, Dm);
         const unsigned nbl = blocks_for(n, kTile);
         int cur = 0;
+        if (c->sort_onesweep && c->sort_passes > 0) {
+            const int P = c->sort_passes;
+            const int64_t words = (int64_t)P * nbl * kRadix;
+            hipLaunchKernelGGL(radix_zero, dim3(std::min<unsigned>(1024, blocks_for(words, kBlock))), dim3(kBlock), 0, st,
+                               c->os_ghist, c->os_status, words, c->os_counter);
+            hipLaunchKernelGGL(radix_hist_all, dim3(std::min<unsigned>(512, nbl)), dim3(kBlock), 0, st, c->keys[0], n, P,
+                               c->os_ghist, c->os_status, words, c->os_counter);
+            for (int p = 0; p < P; ++p) {
+                hipLaunchKernelGGL(radix_onesweep, dim3(nbl), dim3(kBlock), 0, st, c->keys[cur], c->vals[cur],
+                                   c->keys[cur ^ 1], c->vals[cur ^ 1], c->os_ghist + p * kRadix,
+                                   c->os_status + (int64_t)p * nbl * kRadix, c->os_counter + p, c->os_err, n,
+                                   p * kRadixBits);
+                cur ^= 1;
+            }
+        } else
         for (int p = 0; p < c->sort_passes; ++p) {
             const int shift = p * kRadixBits;
             hipLaunchKernelGGL(radix_hist, dim3(nbl), dim3(kBlock), 0, st, c->keys[cur], c->radix_counts, n, shift,
@@ -256,8 +274,11 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted)
 int check_overflow(bh_ctx *c)
 {
     TreeCounters h{};
+    uint32_t sort_err = 0;
     BH_HIP(c, hipMemcpyAsync(&h, c->ctr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    BH_HIP(c, hipMemcpyAsync(&sort_err, c->os_err, sizeof(sort_err), hipMemcpyDeviceToHost, c->stream));
     BH_HIP(c, hipStreamSynchronize(c->stream));
+    if (sort_err) return fail(c, BH_ERR_DEVICE, "radix sort look-back timed out (inter-workgroup wait exceeded its bound)");
     if (h.overflow || (int64_t)h.n_internal > c->internal_cap)
         return fail(c, BH_ERR_CAPACITY, "tree needs " + std::to_string(1 + 4 * (int64_t)h.n_internal) +
                                         " nodes, node_capacity is " + std::to_string(c->node_cap));
@@ -301,6 +322,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     c->sort_passes = (2 * c->Dm + kRadixBits - 1) / kRadixBits;
     if (const char *e = std::getenv("BH_WALK_PIPE")) c->walk_mode = std::atoi(e);
     if (const char *e = std::getenv("BH_WALK_XCD")) c->walk_xcd = std::atoi(e) != 0;
+    if (const char *e = std::getenv("BH_SORT_ONESWEEP")) c->sort_onesweep = std::atoi(e) != 0;
     auto bail = [&](int rc) { g_create_error = c->err; bh_destroy(c); return rc; };
 
     if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(BH_ERR_DEVICE); }
@@ -330,7 +352,10 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     A(&c->cnt, cap + 1);
     { const size_t nbl = blocks_for(cap, kTile);
       A(&c->radix_counts, (size_t)kRadix * nbl);
-      A(&c->bsum_sort, kRadix + 8); }
+      A(&c->bsum_sort, kRadix + 8);
+      c->os_status_words = (int64_t)kMaxPasses * nbl * kRadix;
+      A(&c->os_status, c->os_status_words); A(&c->os_ghist, kMaxPasses * kRadix); A(&c->os_counter, kMaxPasses);
+      A(&c->os_err, 4); }
     A(&c->bsum_u32, blocks_for(cap + 1, kTile) + 8);
     A(&c->partial, 4 * (std::max<size_t>(1024, blocks_for(cap, kBlock)) + 2)); A(&c->box, 4);
     A(&c->ctr, 1);
@@ -345,6 +370,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
         A(&c->terms, cap + 1); A(&c->bsum_d3, blocks_for(cap + 1, kTile) + 8);
     }
     if (rc) return bail(rc);
+    if (hipMemset(c->os_err, 0, 16) != hipSuccess) { c->err = "hipMemset failed"; return bail(BH_ERR_DEVICE); }
     for (auto &e : c->ev_step) if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(BH_ERR_DEVICE); }
     for (auto &e : c->ev_build) if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(BH_ERR_DEVICE); }
     *out = c;
