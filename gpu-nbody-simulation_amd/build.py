@@ -50,7 +50,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src, extra in UNITS:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall",
-               "-Wno-unused-function", *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+               "-Wno-unused-function", *extra, *os.environ.get("BHGPU_EXTRA_FLAGS", "").split(),
+               "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)

@@ -157,7 +157,7 @@ int enqueue_build_t(bh_ctx *c)
         // 2. keys by fp64 bisection, 3. stable radix sort
         hipLaunchKernelGGL((keys_kernel<Real2>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos, c->box,
                            c->keys[0], c->vals[0], n, Dm);
-        const unsigned nbl = blocks_for(n, kTile);
+        const unsigned nbl = blocks_for(n, kSortTile);
         int cur = 0;
         if (c->sort_onesweep && c->sort_passes > 0) {
             const int P = c->sort_passes;
@@ -350,7 +350,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     { char *t; A(&t, cap * 2 * rs); c->force = t; }
     A(&c->keys[0], cap); A(&c->keys[1], cap); A(&c->vals[0], cap); A(&c->vals[1], cap);
     A(&c->cnt, cap + 1);
-    { const size_t nbl = blocks_for(cap, kTile);
+    { const size_t nbl = blocks_for(cap, kSortTile);
       A(&c->radix_counts, (size_t)kRadix * nbl);
       A(&c->bsum_sort, kRadix + 8);
       c->os_status_words = (int64_t)kMaxPasses * nbl * kRadix;

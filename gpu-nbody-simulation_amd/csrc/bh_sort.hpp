@@ -71,6 +71,11 @@ __global__ __launch_bounds__(kBlock) void scan_apply(const T *in, T *out, const 
     }
 }
 
+#ifndef BH_SORT_ITEMS
+#define BH_SORT_ITEMS 8
+#endif
+constexpr int kSortItems = BH_SORT_ITEMS;          // keys per thread in the sort kernels
+constexpr int kSortTile = kBlock * kSortItems;
 constexpr int kRadixBits = 8;
 
 // grid = 256 workgroups (one per digit): counts[d][*] -> exclusive prefix in place, total aside
@@ -101,9 +106,9 @@ __global__ __launch_bounds__(kBlock) void radix_hist(const uint64_t *__restrict_
     __shared__ uint32_t h[kRadix];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * kTile;
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
 #pragma unroll
-    for (int r = 0; r < kItems; ++r) {
+    for (int r = 0; r < kSortItems; ++r) {
         const int64_t i = base + r * kBlock + threadIdx.x;
         if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (kRadix - 1)], 1u);
     }
@@ -134,10 +139,10 @@ __global__ __launch_bounds__(kBlock) void radix_scatter(const uint64_t *__restri
     for (int k = 0; k < kWavesPerBlock; ++k) wcnt[k][t] = 0;
     __syncthreads();
 
-    const int64_t base = (int64_t)blockIdx.x * kTile;
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
     const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
 #pragma unroll 1
-    for (int r = 0; r < kItems; ++r) {
+    for (int r = 0; r < kSortItems; ++r) {
         const int64_t i = base + r * kBlock + t;
         const bool valid = i < n;
         const uint64_t key = valid ? kin[i] : 0ull;
@@ -242,11 +247,11 @@ __global__ __launch_bounds__(kBlock) void radix_onesweep(const uint64_t *__restr
     for (int k = 0; k < kWavesPerBlock; ++k) wcnt[k][t] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
-    const int64_t base = (int64_t)tile * kTile;
+    const int64_t base = (int64_t)tile * kSortTile;
 
     // 1. local histogram
 #pragma unroll
-    for (int r = 0; r < kItems; ++r) {
+    for (int r = 0; r < kSortItems; ++r) {
         const int64_t i = base + r * kBlock + t;
         if (i < n) atomicAdd(&hist[(uint32_t)(kin[i] >> shift) & (kRadix - 1)], 1u);
     }
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void radix_onesweep(const uint64_t *__restr
     // 4. stable scatter of the tile (per-round ballot matching, as radix_scatter)
     const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
 #pragma unroll 1
-    for (int r = 0; r < kItems; ++r) {
+    for (int r = 0; r < kSortItems; ++r) {
         const int64_t i = base + r * kBlock + t;
         const bool valid = i < n;
         const uint64_t key = valid ? kin[i] : 0ull;

@@ -20,7 +20,6 @@ TREE_NODE_DTYPE = np.dtype(
 
 FLAG_WALK_STATS = 1 << 0
 FLAG_LDS_STACK = 1 << 1
-FLAG_NO_GRAPH = 1 << 2
 
 
 class Precision(enum.IntEnum):

@@ -51,7 +51,6 @@ typedef enum bh_precision {
 #define BH_FLAG_WALK_STATS   (1u << 0)  /* count visits/interactions in the walk (slower)   */
 #define BH_FLAG_LDS_STACK    (1u << 1)  /* fp32 walk: LDS traversal stack instead of the
                                            register-lane stack (A/B switch)  */
-#define BH_FLAG_NO_GRAPH     (1u << 2)  /* launch kernels eagerly instead of via hipGraph    */
 
 /* Replaces the compile-time configuration of project.cu:1-11, 27-35, 60-62. */
 typedef struct bh_config {

@@ -194,3 +194,29 @@ def test_full_size_properties():
     scale = (m[:, None] * np.abs(a1)).sum()
     assert net <= 2e-3 * scale
     assert 300 < st.interactions / n < 600 and 10 < st.wave_nodes / n < 25
+
+
+def test_direct_sum_limit_against_main_approach_1(gold, init1024):
+    """BASELINE config[0] names main_approach_1.cpp (O(N^2) direct sum, fp64).  With theta -> 0 every
+    cell is opened and the fp32 walk degenerates to the direct sum: forces of step 0 within fp32
+    rounding of the REFERENCE's; the 10-step trajectory within the stated percentiles."""
+    m, p, v = init1024
+    g = gold("ref_ma1_1024")
+    with engine(1024, max_depth=21, theta=1e-6, reference_compat=False) as e:
+        e.upload(p, v, m)
+        e.compute_forces()
+        f = e.forces()
+        e.step(10)
+        pp, vv = e.download()
+    r = rel_err(f, g["forces_0"])
+    assert np.median(r) < 5e-6 and r.max() < 5e-4
+    # 10 steps.  The shipped bodies include pairs 1e-5 apart (SURVEY 0 fact 4); fp32 positions resolve
+    # 7e-9, so the relative error of such a pair's separation -- and of its mutual force -- is ~1e-3 and
+    # grows with every encounter: the tail is physics + precision, not a bug.  Measured on MI355X:
+    # position error quantiles 50/90/99/max = 1.5e-8 / 1.6e-6 / 5.1e-5 / 7.9e-4.
+    err = np.abs(pp - g["pos_after_9"]).max(axis=1)
+    assert np.median(err) <= 1e-7 and np.quantile(err, 0.9) <= 1e-5
+    assert np.quantile(err, 0.99) <= 3e-4 and err.max() <= 5e-3
+    dv, dv_ref = vv - v, g["vel_after_9"] - v
+    rv = np.linalg.norm(dv - dv_ref, axis=1) / np.linalg.norm(dv_ref, axis=1)
+    assert np.median(rv) < 1e-4 and np.quantile(rv, 0.9) < 5e-3
