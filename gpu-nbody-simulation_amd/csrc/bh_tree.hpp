@@ -433,6 +433,10 @@ __global__ __launch_bounds__(kBlock) void nodes_exact_kernel(
 //   * single bodies come from the sorted copies (neighbouring addresses), not through perm;
 //   * one thread per CELL and coalesced LDS-staged stores (see the kernel); LDS (36 KB per
 //     workgroup: key window + staging) bounds residency at 4 workgroups per CU.
+// A depth-cap cell holding more bodies than this is aggregated as the reference does even with
+// reference_compat off: a direct sum over it would cost O(bodies) per visiting body, and a
+// degenerate input (one body at infinity collapses every key) would turn one step into O(N^2).
+constexpr int kMaxBucket = 1024;
 constexpr int kKeyHalo = 768;
 constexpr int kKeyWin = kBlock + 1 + kKeyHalo;
 
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(kBlock, 4) void nodes_fast_kernel(
                 const bool one = (n == 1);
                 const float cx = one ? spos[0].x : (float)(t.b / t.a), cy = one ? spos[0].y : (float)(t.c / t.a);
                 const float m = (t.a > 1e-15) ? (one ? smass[0] : (float)t.a) : 0.f;
-                const bool bucket = (n > 1) && !COMPAT;
+                const bool bucket = (n > 1) && (n <= kMaxBucket) && !COMPAT;
                 put(0, 0, cx, cy, m, bucket ? INFINITY : 0.f, bucket ? -2 : -1);
                 aux[0] = NodeAux{0, (int32_t)n};
             }
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(kBlock, 4) void nodes_fast_kernel(
             const double mm = hi_s.a - lo_s.a;
             m = (float)mm; cx = (float)((hi_s.b - lo_s.b) / mm); cy = (float)((hi_s.c - lo_s.c) / mm);
             if (d + 1 == Dm) {                                   // depth-cap cell
-                if (!COMPAT) { thr = INFINITY; child = -(4 * quad + c) - 2; }
+                if (!COMPAT && nc <= kMaxBucket) { thr = INFINITY; child = -(4 * quad + c) - 2; }
             } else {                                             // subdivided cell
                 const int Lpc = (bc == 0) ? -1 : shared_levels(K(bc - 1), K(bc), Dm);
                 child = (int32_t)(off[bc] + (uint32_t)((d + 1) - (Lpc + 1))) + 1;

@@ -66,8 +66,9 @@ typedef struct bh_config {
                                    artefact included).  0: F64_EXACT keeps the aggregation but
                                    uses main_approach_2.cpp's `occ == i` skip only (with
                                    max_depth 32 this is the uncapped tree of ma2.cpp); F32
-                                   sums a depth-cap cell holding several bodies body by body
-                                   (bucket leaf), so no body interacts with its own cell.     */
+                                   sums a depth-cap cell holding several (<= 1024) bodies body
+                                   by body (bucket leaf), so no body interacts with its own
+                                   cell; larger cells (degenerate inputs) are aggregated.     */
     int32_t  device;            /* HIP device ordinal                                       */
     int32_t  n_threads;         /* N_THREADS, project.cu:5-7.  Accepted so the scaling
                                    scripts' parameter has somewhere to go; the CDNA4 launch

@@ -220,3 +220,20 @@ def test_direct_sum_limit_against_main_approach_1(gold, init1024):
     dv, dv_ref = vv - v, g["vel_after_9"] - v
     rv = np.linalg.norm(dv - dv_ref, axis=1) / np.linalg.norm(dv_ref, axis=1)
     assert np.median(rv) < 1e-4 and np.quantile(rv, 0.9) < 5e-3
+
+
+def test_degenerate_input_stays_bounded():
+    """One body at infinity collapses every key into one depth-cap cell.  With compat off that cell
+    would be a bucket of N bodies (an O(N^2) step that looks like a hang); cells above 1,024 bodies
+    are aggregated instead, so the step returns promptly and finitely for the regular bodies."""
+    import time
+    n = 200000
+    m, p, v = IC.make("uniform", n, 6)
+    p[17] = [np.inf, 0.0]
+    with engine(n, max_depth=21, reference_compat=False) as e:
+        e.upload(p, v, m)
+        t0 = time.time()
+        e.step(2)
+        e.sync()
+        assert time.time() - t0 < 5.0
+        assert e.stats().n_nodes <= 1 + 4 * 21
