@@ -43,7 +43,8 @@ struct bh_ctx {
     bool uploaded = false, tree_valid = false;
     int64_t internal_cap = 0, node_cap = 0;
     int sort_passes = 0;
-    int walk_mode = 0; bool walk_xcd = false;  // BH_WALK_PIPE / BH_WALK_XCD override (A/B)
+    int walk_mode = 0; bool walk_xcd = false;
+    bool hilbert = false;                // fp32 mode: Hilbert-ordered keys (BH_HILBERT=0 disables, A/B)  // BH_WALK_PIPE / BH_WALK_XCD override (A/B)
     int partial_count = 0;         // > 0: partial[] holds per-workgroup min/max of the current positions
 
     // caller-order state (double2/double or float2/float)
@@ -155,8 +156,12 @@ int enqueue_build_t(bh_ctx *c)
 
     if (n > 0) {
         // 2. keys by fp64 bisection, 3. stable radix sort
-        hipLaunchKernelGGL((keys_kernel<Real2>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos, c->box,
-                           c->keys[0], c->vals[0], n, Dm);
+        if (c->hilbert)
+            hipLaunchKernelGGL((keys_kernel<Real2, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
+                               c->box, c->keys[0], c->vals[0], n, Dm);
+        else
+            hipLaunchKernelGGL((keys_kernel<Real2, false>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
+                               c->box, c->keys[0], c->vals[0], n, Dm);
         const unsigned nbl = blocks_for(n, kSortTile);
         int cur = 0;
         if (c->sort_onesweep && c->sort_passes > 0) {
@@ -323,6 +328,8 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     if (const char *e = std::getenv("BH_WALK_PIPE")) c->walk_mode = std::atoi(e);
     if (const char *e = std::getenv("BH_WALK_XCD")) c->walk_xcd = std::atoi(e) != 0;
     if (const char *e = std::getenv("BH_SORT_ONESWEEP")) c->sort_onesweep = std::atoi(e) != 0;
+    c->hilbert = !c->exact;
+    if (const char *e = std::getenv("BH_HILBERT")) c->hilbert = !c->exact && std::atoi(e) != 0;
     auto bail = [&](int rc) { g_create_error = c->err; bh_destroy(c); return rc; };
 
     if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(BH_ERR_DEVICE); }
@@ -616,9 +623,9 @@ static int export_tree_host(bh_ctx *c, std::vector<bh_tree_node> &out, std::vect
         BH_HIP(c, hipMemcpy(qf.data(), c->qf, nq * sizeof(QuadF), hipMemcpyDeviceToHost));
         BH_HIP(c, hipMemcpy(aux.data(), c->aux, 4 * nq * sizeof(NodeAux), hipMemcpyDeviceToHost));
     }
-    struct Item { int32_t node; int32_t depth; int64_t parent_out; int slot; double x0, x1, y0, y1; };
+    struct Item { int32_t node; int32_t depth; int64_t parent_out; int slot; double x0, x1, y0, y1; int state; };
     std::vector<Item> stack;
-    stack.push_back({0, 0, -1, 0, box[0], box[1], box[2], box[3]});
+    stack.push_back({0, 0, -1, 0, box[0], box[1], box[2], box[3], 0});
     out.clear(); depth.clear();
     out.reserve(nn); depth.reserve(nn);
     while (!stack.empty()) {
@@ -652,9 +659,13 @@ static int export_tree_host(bh_ctx *c, std::vector<bh_tree_node> &out, std::vect
         if (child >= 0) {
             const double mx = (it.x0 + it.x1) / 2.0, my = (it.y0 + it.y1) / 2.0;
             for (int k = 3; k >= 0; --k) {          // push reversed: child 0 is visited first
-                Item ch{child + k, it.depth + 1, me, k,
+                // k is the GEOMETRIC child index (the reference's order); with Hilbert keys the
+                // sibling sits in slot H[state][k] of the quad
+                const int slot = c->hilbert ? hilbert_digit(it.state, k) : k;
+                Item ch{child + slot, it.depth + 1, me, k,
                         (k & 1) ? mx : it.x0, (k & 1) ? it.x1 : mx,
-                        (k & 2) ? my : it.y0, (k & 2) ? it.y1 : my};
+                        (k & 2) ? my : it.y0, (k & 2) ? it.y1 : my,
+                        c->hilbert ? hilbert_next(it.state, k) : 0};
                 stack.push_back(ch);
             }
         }
