@@ -5,7 +5,7 @@ TAG=$1; shift
 OUT=gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline "$@" > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-secondary "$@" > $OUT/trace.log 2>&1
 tail -1 $OUT/trace.log
 python3 - <<PY
 import csv, glob
