@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--lds-stack", action="store_true", help="A/B: LDS traversal stack variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second distribution")
+    ap.add_argument("--decomposition", choices=["let", "replicated"], default="let",
+                    help="multi-GPU scheme (DESIGN.md 9): 'let' = ORB partition, local trees, locally-"
+                         "essential-tree exchange (bodies live on one rank only); 'replicated' = every rank "
+                         "builds the whole tree and walks a share, one all_gather per step")
     ap.add_argument("--force-sharded", action="store_true",
                     help="take the multi-GPU exchange path (step_local, all_gather, scatter) even on one rank")
     ap.add_argument("--cpu-sample", type=int, default=0,
@@ -105,7 +109,8 @@ def main():
     import torch.distributed as dist
     import gpu_nbody_simulation_amd as G
     from gpu_nbody_simulation_amd import initial_conditions as IC
-    from gpu_nbody_simulation_amd.distributed import ShardedStepper, init_process_group_from_env
+    from gpu_nbody_simulation_amd.distributed import (LetStepper, ShardedStepper, init_process_group_from_env,
+                                                      partition_orb)
     from gpu_nbody_simulation_amd.engine import FLAG_LDS_STACK, FLAG_WALK_STATS
 
     rank, local, world = init_process_group_from_env("nccl")
@@ -126,11 +131,24 @@ def main():
     flags = FLAG_LDS_STACK if a.lds_stack else 0
     cfg = G.BhConfig(capacity=n, theta=a.theta, max_depth=a.max_depth, precision=G.Precision.F32,
                      reference_compat=False, device=local, flags=flags)
+    sharded = world > 1 or a.force_sharded
+    use_let = sharded and a.decomposition == "let"
+    let_info = None
+    if use_let:
+        # every rank derives the same partition from the same synthetic state and keeps its part only
+        mine = partition_orb(pos, world)[rank]
+        cfg = G.BhConfig(capacity=max(len(mine), 1), theta=a.theta, max_depth=a.max_depth,
+                         precision=G.Precision.F32, reference_compat=False, device=local, flags=flags)
     eng = G.BarnesHutEngine(cfg)
-    if world > 1 or a.force_sharded:
+    if sharded:
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    eng.upload(pos, vel, mass)                       # bodies resident in HBM from here on
-    stepper = ShardedStepper(eng, rank, world, n, dev, force_exchange=a.force_sharded)
+    if use_let:
+        eng.upload(pos[mine], vel[mine], mass[mine])  # this rank's bodies, resident in HBM from here on
+        stepper = LetStepper(eng, rank, world, let_cap=1 << 14, device=dev)
+        cap = stepper.autotune()                      # block size from the measured LET sizes (untimed)
+    else:
+        eng.upload(pos, vel, mass)                    # bodies resident in HBM from here on
+        stepper = ShardedStepper(eng, rank, world, n, dev, force_exchange=a.force_sharded)
 
     def sync_all():
         eng.sync()
@@ -142,7 +160,7 @@ def main():
         stepper.step()
     sync_all()
     t0 = time.perf_counter()
-    if world == 1 and not a.force_sharded:
+    if not sharded:
         eng.step(a.steps)                            # K steps enqueued back to back on one stream
     else:
         for _ in range(a.steps):
@@ -153,12 +171,27 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if use_let:
+        largest = stepper.check()                    # raises if a LET outgrew its block: run invalid
+        let_info = {"let_cap_quads": cap, "largest_let_quads": largest,
+                    "all_to_all_bytes_per_rank_per_step": cap * 80 * (world - 1),
+                    "bodies_on_rank0": int(len(mine))}
 
     st = eng.stats()                                 # HIP events recorded inside the timed region
-    walk_ms = st.walk_ms if (world == 1 and not a.force_sharded) else None
+    walk_ms = st.walk_ms if not sharded else None
 
     # ---- untimed: counters of one walk on the final state (second engine, stats variant) --------
     pf, vf = eng.download()
+    if use_let:
+        # the final state lives in pieces: collect it on every rank for the untimed stats walk
+        pieces = [None] * world
+        if world > 1:
+            dist.all_gather_object(pieces, (mine, pf, vf))
+        else:
+            pieces = [(mine, pf, vf)]
+        pf, vf = np.empty((n, 2)), np.empty((n, 2))
+        for ix, pp, vv in pieces:
+            pf[ix], vf[ix] = pp, vv
     out = None
     if rank == 0:
         with G.BarnesHutEngine(G.BhConfig(capacity=n, theta=a.theta, max_depth=a.max_depth,
@@ -198,12 +231,16 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.init}_N{n}_theta{a.theta}", "n_bodies": n, "theta": a.theta,
                        "max_depth": a.max_depth, "init": a.init, "seed": a.seed,
-                       "parallelism": "1 GPU" if world == 1 else f"morton-range x{world}, all_gather/step"},
+                       "parallelism": "1 GPU" if not sharded else
+                       (f"orb x{world}, local trees + LET all_to_all/step" if use_let
+                        else f"replicated build, hilbert-range walk x{world}, all_gather/step")},
             "minteractions_per_s": ss.interactions * a.steps / elapsed / 1e6,
             "interactions_per_body": ss.interactions / n,
             "build_ms": st.build_ms, "walk_ms": st.walk_ms, "n_nodes": ss.n_nodes,
             "roofline": roof,
         }
+        if let_info:
+            out["let"] = let_info
         if world == 1 and not a.no_secondary:
             # the uniform distribution next to the Plummer one (same N, theta, steps)
             other = "uniform" if a.init == "plummer" else "plummer"

@@ -17,6 +17,7 @@
 #include "bh_tree.hpp"
 #include "bh_walk_exact.hpp"
 #include "bh_init.hpp"
+#include "bh_let.hpp"
 #include "bh_walk_fast.h"
 
 using namespace bh;
@@ -75,6 +76,14 @@ struct bh_ctx {
 
     // ownership (multi-GPU): sorted range [lo, hi) = rank's share
     int rank = 0, world = 1;
+    // distributed step with locally-essential trees (bh_let_*): this context holds only its own bodies
+    bool let_mode = false, external_box = false;
+    int64_t let_cap = 0, quads_local = 0;
+    uint64_t *needmask = nullptr;
+    uint32_t *let_tsum = nullptr, *let_outidx = nullptr;
+    QuadF *let_send = nullptr;
+    double *lbounds = nullptr, *all_bounds = nullptr;
+    LetCounters *let_ctr = nullptr;
 
     // measurement
     std::vector<hipEvent_t> ev;        // pairs around the walk kernel, one pair per step
@@ -119,10 +128,18 @@ int dev_alloc(bh_ctx *c, T **out, size_t count)
     return BH_OK;
 }
 
+inline void dev_free(bh_ctx *c, void *p)
+{
+    if (!p) return;
+    auto it = std::find(c->allocs.begin(), c->allocs.end(), p);
+    if (it != c->allocs.end()) { c->allocs.erase(it); (void)hipFree(p); }
+}
+
 inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 void owned_range(const bh_ctx *c, int64_t *lo, int64_t *hi)
 {
+    if (c->let_mode) { *lo = 0; *hi = c->n; return; }     // a LET context holds only its own bodies
     // equal chunks of ceil(n/world) sorted slots rounded up to the workgroup size (the last ranks
     // may own fewer, or none): every rank then forms exactly the wavefronts the single-GPU run
     // forms, so per-body summation order -- and therefore every bit of the result -- does not
@@ -146,13 +163,15 @@ int enqueue_build_t(bh_ctx *c)
 
     // 1. root box (ComputeRootBounds, project.cu:536-573); the per-workgroup partials usually
     //    come from the previous step's walk epilogue
-    if (c->partial_count <= 0) {
-        const unsigned nbb = std::max(1u, std::min(1024u, blocks_for(n, kBlock)));
-        hipLaunchKernelGGL((bounds_partial<Real2>), dim3(nbb), dim3(kBlock), 0, st, pos, n, c->partial);
-        c->partial_count = (int)nbb;
-    }
-    hipLaunchKernelGGL(bounds_final, dim3(1), dim3(kBlock), 0, st, c->partial, c->partial_count, c->box, c->ctr);
-    c->partial_count = 0;
+    if (!c->external_box) {
+        if (c->partial_count <= 0) {
+            const unsigned nbb = std::max(1u, std::min(1024u, blocks_for(n, kBlock)));
+            hipLaunchKernelGGL((bounds_partial<Real2>), dim3(nbb), dim3(kBlock), 0, st, pos, n, c->partial);
+            c->partial_count = (int)nbb;
+        }
+        hipLaunchKernelGGL(bounds_final, dim3(1), dim3(kBlock), 0, st, c->partial, c->partial_count, c->box, c->ctr);
+        c->partial_count = 0;
+    }   // else: let_box_kernel has set the global box and cleared the counters
 
     if (n > 0) {
         // 2. keys by fp64 bisection, 3. stable radix sort
@@ -268,9 +287,11 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted)
         a.acc_out = (float2 *)c->force; a.ctr = c->ctr;
         a.lo = lo; a.hi = hi; a.G = (float)c->cfg.G; a.dt = (float)c->cfg.dt;
         a.integrate = integrate ? 1 : 0; a.to_sorted = to_sorted ? 1 : 0;
+        a.n_trees = c->let_mode ? c->world : 0; a.self_rank = c->let_mode ? c->rank : -1;
+        a.forest_base = c->quads_local; a.let_cap = c->let_cap;
         // the register-lane stack holds 64 entries; the walk never needs more than 3*Dm + 2
         const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0 || (3 * c->Dm + 2 > kWave);
-        BH_HIP(c, launch_walk_fast(a, lds, stats, c->walk_mode, c->walk_xcd, c->stream));
+        BH_HIP(c, launch_walk_fast(a, lds, stats, c->let_mode ? 0 : c->walk_mode, c->walk_xcd, c->stream));
     }
     if (want_partial) c->partial_count = (int)blocks_for(hi - lo, kBlock);
     return BH_OK;
@@ -831,4 +852,132 @@ int bh_scatter_sorted(bh_ctx *c)
     return BH_OK;
 }
 
+// ---- distributed step with locally-essential trees --------------------------------------------------
+int bh_let_configure(bh_ctx *c, int32_t rank, int32_t world, int64_t let_cap)
+{
+    if (!c || world < 1 || world > kMaxWorld || rank < 0 || rank >= world || let_cap < 1)
+        return fail(c, BH_ERR_ARG, "bh_let_configure: bad rank/world/let_cap (world <= 64)");
+    if (c->exact) return fail(c, BH_ERR_STATE, "bh_let_configure: fp32 mode only");
+    BH_HIP(c, hipSetDevice(c->device));
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = 0;
+    auto A = [&](auto **pp, size_t count) { if (!rc) rc = dev_alloc(c, pp, count); };
+    if (c->let_mode) {
+        // a second call may only change let_cap (LetStepper.autotune: size the blocks from measured counts)
+        if (rank != c->rank || world != c->world)
+            return fail(c, BH_ERR_STATE, "bh_let_configure: rank/world cannot change once configured");
+        if (let_cap == c->let_cap) return BH_OK;
+        dev_free(c, c->qf); dev_free(c, c->let_send);
+        c->qf = nullptr; c->let_send = nullptr;
+    } else {
+        c->rank = rank; c->world = world;
+        c->quads_local = c->internal_cap + 1;
+        const int64_t ntiles = blocks_for(c->quads_local, kTile);
+        dev_free(c, c->qf);              // the single-tree node array: the forest below replaces it
+        c->qf = nullptr;
+        A(&c->needmask, (size_t)c->quads_local);
+        A(&c->let_tsum, (size_t)world * ntiles);
+        A(&c->let_outidx, (size_t)world * c->quads_local);
+        A(&c->lbounds, 4); A(&c->all_bounds, 4 * (size_t)world);
+        A(&c->let_ctr, 1);
+    }
+    c->let_cap = let_cap;
+    A(&c->qf, (size_t)(c->quads_local + (int64_t)world * let_cap));
+    A(&c->let_send, (size_t)world * let_cap);
+    if (rc) return rc;
+    BH_HIP(c, hipMemset(c->let_ctr, 0, sizeof(LetCounters)));
+    c->let_mode = true;
+    c->external_box = true;
+    c->tree_valid = false;
+    return BH_OK;
+}
+
+int bh_let_bounds(bh_ctx *c)
+{
+    if (!c || !c->let_mode) return fail(c, BH_ERR_STATE, "bh_let_bounds: call bh_let_configure first");
+    if (!c->uploaded) return fail(c, BH_ERR_STATE, "bh_let_bounds before bh_upload");
+    BH_HIP(c, hipSetDevice(c->device));
+    if (c->partial_count <= 0) {
+        const unsigned nbb = std::max(1u, std::min(1024u, blocks_for(c->n, kBlock)));
+        hipLaunchKernelGGL((bounds_partial<float2>), dim3(nbb), dim3(kBlock), 0, c->stream, (const float2 *)c->pos,
+                           c->n, c->partial);
+        c->partial_count = (int)nbb;
+    }
+    hipLaunchKernelGGL(let_local_bounds_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->partial, c->partial_count,
+                       c->lbounds);
+    c->partial_count = 0;
+    BH_HIP(c, hipGetLastError());
+    return BH_OK;
+}
+
+int bh_let_pointers(bh_ctx *c, void **lbounds, void **all_bounds, void **send, void **recv, int64_t *block_bytes)
+{
+    if (!c || !c->let_mode) return fail(c, BH_ERR_STATE, "bh_let_pointers: call bh_let_configure first");
+    if (lbounds) *lbounds = c->lbounds;
+    if (all_bounds) *all_bounds = c->all_bounds;
+    if (send) *send = c->let_send;
+    if (recv) *recv = c->qf + c->quads_local;
+    if (block_bytes) *block_bytes = c->let_cap * (int64_t)sizeof(QuadF);
+    return BH_OK;
+}
+
+int bh_let_build(bh_ctx *c)
+{
+    if (!c || !c->let_mode) return fail(c, BH_ERR_STATE, "bh_let_build: call bh_let_configure first");
+    if (!c->uploaded) return fail(c, BH_ERR_STATE, "bh_let_build before bh_upload");
+    BH_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    hipLaunchKernelGGL(let_box_kernel, dim3(1), dim3(64), 0, st, c->all_bounds, c->world, c->box, c->ctr, c->let_ctr);
+    int rc = enqueue_build(c);
+    if (rc) return rc;
+    const int64_t nq = c->quads_local;
+    const int ntiles = (int)blocks_for(nq, kTile);
+    hipLaunchKernelGGL(let_mark_kernel, dim3(blocks_for(nq, kBlock)), dim3(kBlock), 0, st, c->qf, c->all_bounds,
+                       c->world, c->rank, c->ctr, c->internal_cap, c->needmask);
+    hipLaunchKernelGGL(let_count_kernel, dim3(ntiles), dim3(kBlock), 0, st, c->needmask, c->world, c->ctr,
+                       c->internal_cap, c->let_tsum, ntiles);
+    hipLaunchKernelGGL(let_rowscan_kernel, dim3(c->world), dim3(kBlock), 0, st, c->let_tsum, ntiles, c->let_ctr,
+                       (uint32_t)c->let_cap);
+    hipLaunchKernelGGL(let_apply_kernel, dim3(ntiles), dim3(kBlock), 0, st, c->needmask, c->world, c->ctr,
+                       c->internal_cap, c->let_tsum, ntiles, c->let_outidx, nq);
+    hipLaunchKernelGGL(let_pack_kernel, dim3(blocks_for(nq, kBlock)), dim3(kBlock), 0, st, c->qf, c->needmask,
+                       c->let_outidx, nq, c->world, c->rank, c->ctr, c->internal_cap, c->let_send,
+                       (uint32_t)c->let_cap, c->quads_local + (int64_t)c->rank * c->let_cap);
+    BH_HIP(c, hipGetLastError());
+    return BH_OK;
+}
+
+int bh_let_walk(bh_ctx *c)
+{
+    if (!c || !c->let_mode) return fail(c, BH_ERR_STATE, "bh_let_walk: call bh_let_configure first");
+    if (!c->tree_valid) return fail(c, BH_ERR_STATE, "bh_let_walk before bh_let_build");
+    BH_HIP(c, hipSetDevice(c->device));
+    int rc = enqueue_walk(c, true, false);
+    if (rc) return rc;
+    c->steps_done += 1;
+    return BH_OK;
+}
+
+int bh_let_forces(bh_ctx *c)
+{
+    if (!c || !c->let_mode) return fail(c, BH_ERR_STATE, "bh_let_forces: call bh_let_configure first");
+    if (!c->tree_valid) return fail(c, BH_ERR_STATE, "bh_let_forces before bh_let_build");
+    BH_HIP(c, hipSetDevice(c->device));
+    return enqueue_walk(c, false, false);
+}
+
+int bh_let_counts(bh_ctx *c, uint32_t *counts, int32_t *overflow)
+{
+    if (!c || !c->let_mode || !counts) return fail(c, BH_ERR_STATE, "bh_let_counts: not in LET mode");
+    BH_HIP(c, hipSetDevice(c->device));
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+    LetCounters h{};
+    BH_HIP(c, hipMemcpy(&h, c->let_ctr, sizeof(h), hipMemcpyDeviceToHost));
+    for (int r = 0; r < c->world; ++r) counts[r] = h.count[r];
+    if (overflow) { *overflow = (int32_t)h.overflow; return BH_OK; }   // the caller inspects the flag
+    if (h.overflow) return fail(c, BH_ERR_CAPACITY, "a locally-essential tree exceeded let_cap");
+    return BH_OK;
+}
+
 }  // extern "C"
+

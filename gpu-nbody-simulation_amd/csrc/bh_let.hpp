@@ -1,0 +1,244 @@
+// bh_let.hpp -- locally-essential-tree (LET) extraction for the distributed step.
+// The reference is single-GPU; this is new design.
+//
+// Each rank owns a set of bodies (initially a contiguous chunk of the Hilbert order, so a compact
+// region) and builds its LOCAL tree with the usual pipeline, but under the GLOBAL root box, so its
+// cells are cells of the global grid.  The force on a body is the sum of its walks over the W local
+// trees (a forest); per-body MAC as everywhere else.  For the remote trees a rank does not need
+// whole trees, only the part its bodies can open:
+//
+//   a node of rank r's tree can be opened by SOME body of peer q only if
+//        dist^2(node COM, bounding box of q's bodies) <= (size/theta)^2 = thr
+//   (every body of q is at least that far away; a body opens a node iff d^2 <= thr).
+//
+// That test is local to the node, so marking is one pass over the quads with no traversal:
+//   let_mark   : needmask[child quad] = {peers that can open the parent node}   (64 peers max)
+//   let_count  : per (peer, tile) number of needed quads
+//   let_rowscan: per peer exclusive scan over tiles, total = LET size
+//   let_apply  : outidx[peer][quad] = position of the quad in that peer's LET
+//   let_pack   : copy every needed quad into the peer's send block, child links rewritten to the
+//                RECEIVER's index space (its forest array places the LET of sender r at
+//                local_quads + r * let_cap), links to quads the peer cannot open cut (-1: the node
+//                is then always accepted by that peer's bodies), buckets turned into aggregates.
+// (A quad whose ancestor chain is cut is packed but unreachable: a few percent of waste, no
+// traversal needed.)  Correctness does not depend on the domains being compact or disjoint --
+// only the LET sizes do.
+#pragma once
+
+#include "bh_nodes.hpp"
+#include "bh_prims.hpp"
+
+namespace bh {
+
+constexpr int kMaxWorld = 64;
+
+struct LetCounters {
+    uint32_t count[kMaxWorld];   // quads packed for each peer
+    uint32_t overflow;           // some LET exceeded let_cap
+    uint32_t pad[3];
+};
+
+// all_bounds: world x {xmin, xmax, ymin, ymax} raw (unpadded) bounds of every rank's bodies.
+// One thread: global box with the reference's padding (project.cu:553-570).
+__global__ void let_box_kernel(const double *__restrict__ all_bounds, int world, double *__restrict__ box,
+                               TreeCounters *ctr, LetCounters *lc)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
+    for (int r = 0; r < world; ++r) {
+        const double a = all_bounds[4 * r], b = all_bounds[4 * r + 1], c = all_bounds[4 * r + 2], d = all_bounds[4 * r + 3];
+        xlo = (a < xlo) ? a : xlo;  xhi = (xhi < b) ? b : xhi;
+        ylo = (c < ylo) ? c : ylo;  yhi = (yhi < d) ? d : yhi;
+    }
+    const double ex = xhi - xlo, ey = yhi - ylo;
+    const double span = (ex < ey) ? ey : ex;
+    double pad = 0.1 * span;
+    if (span == 0.0) pad = 1e-6;
+    box[0] = xlo - pad; box[1] = xhi + pad; box[2] = ylo - pad; box[3] = yhi + pad;
+    ctr->n_internal = 0; ctr->overflow = 0;
+    ctr->visits = 0; ctr->interactions = 0; ctr->wave_nodes = 0;
+    for (int r = 0; r < kMaxWorld; ++r) lc->count[r] = 0;
+    lc->overflow = 0;
+}
+
+// raw min/max of the local bodies (no padding) from the per-workgroup partials
+__global__ __launch_bounds__(kBlock) void let_local_bounds_kernel(const double *__restrict__ partial, int nb,
+                                                                   double *__restrict__ lbounds)
+{
+    __shared__ double sm[4][kWavesPerBlock];
+    double xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
+    for (int i = threadIdx.x; i < nb; i += kBlock) {
+        const double a = partial[4 * i], b = partial[4 * i + 1], c = partial[4 * i + 2], d = partial[4 * i + 3];
+        xlo = (a < xlo) ? a : xlo;  xhi = (xhi < b) ? b : xhi;
+        ylo = (c < ylo) ? c : ylo;  yhi = (yhi < d) ? d : yhi;
+    }
+    xlo = wave_min(xlo); xhi = wave_max(xhi); ylo = wave_min(ylo); yhi = wave_max(yhi);
+    if (lane_id() == 0) { sm[0][wave_id()] = xlo; sm[1][wave_id()] = xhi; sm[2][wave_id()] = ylo; sm[3][wave_id()] = yhi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+            xlo = (sm[0][w] < xlo) ? sm[0][w] : xlo;  xhi = (xhi < sm[1][w]) ? sm[1][w] : xhi;
+            ylo = (sm[2][w] < ylo) ? sm[2][w] : ylo;  yhi = (yhi < sm[3][w]) ? sm[3][w] : yhi;
+        }
+        lbounds[0] = xlo; lbounds[1] = xhi; lbounds[2] = ylo; lbounds[3] = yhi;
+    }
+}
+
+// thread per local quad k in [0, n_quads): marks the CHILD quads of its four nodes
+__global__ __launch_bounds__(kBlock) void let_mark_kernel(const QuadF *__restrict__ qf,
+                                                           const double *__restrict__ all_bounds, int world,
+                                                           int rank, const TreeCounters *__restrict__ ctr,
+                                                           int64_t internal_cap, uint64_t *__restrict__ needmask)
+{
+    __shared__ float sbox[kMaxWorld][4];
+    if (threadIdx.x < world) {
+        // outward-rounded float copies of the peers' boxes (the test must stay conservative)
+        const double *b = all_bounds + 4 * threadIdx.x;
+        sbox[threadIdx.x][0] = __double2float_rd(b[0]); sbox[threadIdx.x][1] = __double2float_ru(b[1]);
+        sbox[threadIdx.x][2] = __double2float_rd(b[2]); sbox[threadIdx.x][3] = __double2float_ru(b[3]);
+    }
+    __syncthreads();
+    const uint32_t total = ctr->n_internal;
+    if ((int64_t)total > internal_cap) return;
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k > (int64_t)total) return;                       // quads 0..total
+    const uint64_t everyone = (world >= 64 ? ~0ull : ((1ull << world) - 1)) & ~(1ull << rank);
+    if (k == 0) needmask[0] = everyone;                    // every peer gets the root
+    const QuadF q = qf[k];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int32_t child = q.child[s];
+        if (child < 1) continue;                           // leaf, empty or bucket: no child quad
+        const float cx = q.xy[2 * s], cy = q.xy[2 * s + 1];
+        const float thr = q.thr[s] * 1.0001f;              // guard band for fp32 rounding of d^2
+        uint64_t mask = 0;
+        for (int p = 0; p < world; ++p) {
+            if (p == rank) continue;
+            const float dx = fmaxf(fmaxf(sbox[p][0] - cx, cx - sbox[p][1]), 0.f);
+            const float dy = fmaxf(fmaxf(sbox[p][2] - cy, cy - sbox[p][3]), 0.f);
+            if (dx * dx + dy * dy <= thr) mask |= 1ull << p;   // an empty peer box (inf) gives inf: no
+        }
+        needmask[child] = mask;
+    }
+}
+
+// per (peer, tile): number of needed quads in the tile
+__global__ __launch_bounds__(kBlock) void let_count_kernel(const uint64_t *__restrict__ needmask, int world,
+                                                            const TreeCounters *__restrict__ ctr,
+                                                            int64_t internal_cap, uint32_t *__restrict__ tsum,
+                                                            int ntiles)
+{
+    __shared__ uint32_t sm[kWavesPerBlock + 1];
+    const uint32_t total = ctr->n_internal;
+    const int64_t nq = ((int64_t)total > internal_cap) ? 0 : (int64_t)total + 1;
+    const int64_t base = (int64_t)blockIdx.x * kTile;
+    uint64_t m[kItems];
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) {
+        const int64_t k = base + j * kBlock + threadIdx.x;
+        m[j] = (k < nq) ? needmask[k] : 0ull;
+    }
+    for (int p = 0; p < world; ++p) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < kItems; ++j) c += (uint32_t)((m[j] >> p) & 1ull);
+        uint32_t tot;
+        (void)block_exclusive_sum(c, sm, tot);
+        if (threadIdx.x == 0) tsum[(int64_t)p * ntiles + blockIdx.x] = tot;
+    }
+}
+
+// one workgroup per peer: exclusive scan of its tile counts; total = LET size
+__global__ __launch_bounds__(kBlock) void let_rowscan_kernel(uint32_t *__restrict__ tsum, int ntiles,
+                                                              LetCounters *lc, uint32_t let_cap)
+{
+    __shared__ uint32_t sm[kWavesPerBlock + 1];
+    uint32_t *row = tsum + (int64_t)blockIdx.x * ntiles;
+    uint32_t carry = 0;
+    for (int c0 = 0; c0 < ntiles; c0 += kBlock) {
+        const int b = c0 + threadIdx.x;
+        const uint32_t v = (b < ntiles) ? row[b] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_sum(v, sm, tot);
+        if (b < ntiles) row[b] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        lc->count[blockIdx.x] = carry;
+        if (carry > let_cap) lc->overflow = 1;
+    }
+}
+
+// outidx[peer][quad] = rank of the quad among the peer's needed quads (row by row: coalesced)
+__global__ __launch_bounds__(kBlock) void let_apply_kernel(const uint64_t *__restrict__ needmask, int world,
+                                                            const TreeCounters *__restrict__ ctr,
+                                                            int64_t internal_cap, const uint32_t *__restrict__ tsum,
+                                                            int ntiles, uint32_t *__restrict__ outidx,
+                                                            int64_t outidx_stride)
+{
+    __shared__ uint32_t sm[kWavesPerBlock + 1];
+    const uint32_t total = ctr->n_internal;
+    const int64_t nq = ((int64_t)total > internal_cap) ? 0 : (int64_t)total + 1;
+    const int64_t base = (int64_t)blockIdx.x * kTile;
+    for (int p = 0; p < world; ++p) {
+        uint32_t carry = tsum[(int64_t)p * ntiles + blockIdx.x];
+#pragma unroll 1
+        for (int j = 0; j < kItems; ++j) {
+            const int64_t k = base + j * kBlock + threadIdx.x;
+            const uint32_t bit = (k < nq) ? (uint32_t)((needmask[k] >> p) & 1ull) : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_exclusive_sum(bit, sm, tot);
+            if (bit) outidx[(int64_t)p * outidx_stride + k] = carry + ex;
+            carry += tot;
+        }
+    }
+}
+
+// thread per quad: copy it into the send block of every peer that needs it
+__global__ __launch_bounds__(kBlock) void let_pack_kernel(const QuadF *__restrict__ qf,
+                                                           const uint64_t *__restrict__ needmask,
+                                                           const uint32_t *__restrict__ outidx,
+                                                           int64_t outidx_stride, int world, int rank,
+                                                           const TreeCounters *__restrict__ ctr,
+                                                           int64_t internal_cap, QuadF *__restrict__ send,
+                                                           uint32_t let_cap, int64_t recv_base)
+{
+    const uint32_t total = ctr->n_internal;
+    if ((int64_t)total > internal_cap) return;
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k > (int64_t)total) return;
+    const uint64_t mask = needmask[k];
+    if (mask == 0) return;
+    const QuadF q = qf[k];
+    uint64_t cmask[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) cmask[s] = (q.child[s] >= 1) ? needmask[q.child[s]] : 0ull;
+    for (int p = 0; p < world; ++p) {
+        if (!((mask >> p) & 1ull)) continue;
+        const uint32_t o = outidx[(int64_t)p * outidx_stride + k];
+        if (o >= let_cap) continue;                       // overflow is flagged by let_rowscan
+        QuadF out = q;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int32_t c = q.child[s];
+            if (c >= 1) {
+                // child quad needed by p -> its slot in p's forest; otherwise cut: p's bodies all
+                // accept this node (d^2 > thr for every point of p's box)
+                // (a slot past let_cap -- overflow, flagged by let_rowscan -- is cut too, so that a
+                // receiver that walks before the host has seen the flag never leaves its block)
+                int32_t link = -1;
+                if ((cmask[s] >> p) & 1ull) {
+                    const uint32_t co = outidx[(int64_t)p * outidx_stride + c];
+                    if (co < let_cap) link = (int32_t)(recv_base + (int64_t)co);
+                }
+                out.child[s] = link;
+            } else if (c <= -2) {
+                out.child[s] = -1;                        // bucket -> aggregate for remote bodies
+                out.thr[s] = 0.f;
+            }
+        }
+        send[(int64_t)p * let_cap + o] = out;
+    }
+}
+
+}  // namespace bh

@@ -27,6 +27,11 @@ struct WalkFastArgs {
     float G, dt;
     int integrate, to_sorted;
     uint32_t nblocks, xcd_chunk;   // filled by the launcher
+    // forest walk (distributed step): besides the local tree (root quad 0) the bodies walk the
+    // locally-essential trees received from the peers, whose root quads sit at
+    // forest_base + t * let_cap for every t != self_rank, t < n_trees.  n_trees == 0: local tree only.
+    int32_t n_trees, self_rank;
+    int64_t forest_base, let_cap;
 };
 
 // mode: 0 = one stack entry per iteration, 1 = software-pipelined, 2 = two entries per iteration

@@ -232,12 +232,18 @@ __global__ __launch_bounds__(kBlock) void walk_fast_kernel(WalkFastArgs a)
             }
         }
     } else {
-        int32_t base = 0;
-        uint64_t mask = __ballot(valid);
-        do {
-            const QuadRegs q = load_quad(quads + base);
-            eval_quad(q, mask);
-        } while (pop_quad(base, mask));
+        // the local tree, then (distributed step) the locally-essential tree of every peer: one
+        // traversal per tree, so the stack never holds more than one tree's entries
+        const uint64_t everyone = __ballot(valid);
+        for (int32_t t = -1; t < a.n_trees; ++t) {
+            if (t >= 0 && t == a.self_rank) continue;
+            int32_t base = (t < 0) ? 0 : (int32_t)(a.forest_base + (int64_t)t * a.let_cap);
+            uint64_t mask = everyone;
+            do {
+                const QuadRegs q = load_quad(quads + base);
+                eval_quad(q, mask);
+            } while (pop_quad(base, mask));
+        }
     }
 
     float2 np = p;

@@ -8,8 +8,8 @@ shares are exchanged with ONE all_gather per step (positions+velocities, 16 B pe
 fixed-size blocks, in place).  Results are bit-identical to the single-GPU run because a body's
 walk does not depend on who executes it.
 
-The orthogonal-recursive-bisection + locally-essential-tree exchange that removes the replicated
-build is the next step on this path and is described in DESIGN.md.
+Stage 2, LetStepper: orthogonal recursive bisection + locally-essential-tree exchange, which
+removes the replicated build: every rank holds only its own bodies.
 
 The compute object is injected (`ShardedStepper(engine, ...)`): the product passes a
 BarnesHutEngine; the CPU tests pass a stand-in built on the oracle, which lives in tests/ only.
@@ -32,6 +32,36 @@ class _DevPtr:
 
 def wrap_device_f32(ptr: int, nelem: int, device: torch.device) -> torch.Tensor:
     return torch.as_tensor(_DevPtr(ptr, nelem, "<f4"), device=device)
+
+
+def wrap_device(ptr: int, nelem: int, typestr: str, device: torch.device) -> torch.Tensor:
+    return torch.as_tensor(_DevPtr(ptr, nelem, typestr), device=device)
+
+
+def partition_orb(positions, world: int):
+    """Indices of the bodies of every rank by orthogonal recursive bisection: split the longer side of
+    the bounding box at the weighted median (ranks in proportion, so any world size), recurse.  The
+    rank regions are disjoint rectangles, which is what keeps the locally-essential trees small (the
+    LET test is against a peer's bounding box); correctness does not depend on it.  Host, set-up only."""
+    import numpy as np
+    p = np.asarray(positions, dtype=np.float64)
+    out = [None] * world
+
+    def split(idx, r0, nr):
+        if nr == 1:
+            out[r0] = idx
+            return
+        q = p[idx]
+        ext = (q.max(0) - q.min(0)) if len(idx) else np.zeros(2)
+        ax = int(ext[1] > ext[0])
+        nl = nr // 2
+        k = len(idx) * nl // nr
+        order = np.argsort(q[:, ax], kind="stable")
+        split(idx[order[:k]], r0, nl)
+        split(idx[order[k:]], r0 + nl, nr - nl)
+
+    split(np.arange(len(p)), 0, world)
+    return out
 
 
 def init_process_group_from_env(backend: str | None = None):
@@ -86,3 +116,76 @@ class ShardedStepper:
             else:
                 assert self.world == 1
         self.eng.scatter_sorted()
+
+
+class LetStepper:
+    """Distributed step with locally-essential trees (bh_let_* in include/bhgpu.h).
+
+    Every rank holds only its own bodies (engine.upload of its subset, e.g. partition_orb).  Per
+    step: local bounds -> all_gather (32 B per rank) -> local tree under the global box + one
+    compact LET per peer -> all_to_all of fixed-size blocks -> forest walk (own tree + received
+    LETs) + integrate.  No replicated work, two collectives, no host synchronisation.
+
+    The blocks are fixed-size so that no count has to reach the host inside a step; autotune()
+    sizes them once from measured LET sizes, and check() (call it outside timed regions, every so
+    often) raises if a LET has outgrown its block since."""
+
+    def __init__(self, engine, rank: int, world: int, let_cap: int, device: torch.device | None = None):
+        self.eng, self.rank, self.world, self.device = engine, rank, world, device
+        self._configure(let_cap)
+
+    def _configure(self, let_cap: int) -> None:
+        self.let_cap = let_cap
+        self.eng.let_configure(self.rank, self.world, let_cap)
+        lb, ab, sd, rv, nb = self.eng.let_pointers()
+        if isinstance(lb, torch.Tensor):        # stand-in engines hand tensors over directly
+            self.lbounds, self.all_bounds, self.send, self.recv = lb, ab, sd, rv
+        else:
+            self.lbounds = wrap_device(lb, 4, "<f8", self.device)
+            self.all_bounds = wrap_device(ab, 4 * self.world, "<f8", self.device)
+            self.send = wrap_device(sd, self.world * nb, "|u1", self.device)
+            self.recv = wrap_device(rv, self.world * nb, "|u1", self.device)
+
+    def _exchange_bounds(self) -> None:
+        self.eng.let_bounds()
+        if dist.is_initialized() and self.world > 1:
+            dist.all_gather_into_tensor(self.all_bounds, self.lbounds.clone())
+        else:
+            assert self.world == 1
+            self.all_bounds.copy_(self.lbounds)
+
+    def step(self, integrate: bool = True) -> None:
+        self._exchange_bounds()
+        self.eng.let_build()
+        if dist.is_initialized():
+            dist.all_to_all_single(self.recv, self.send)     # block q of send -> block rank of q's recv
+        if integrate:
+            self.eng.let_walk()
+        else:
+            self.eng.let_forces()
+
+    def max_count(self):
+        """(largest LET any rank packed in its last build, whether any overflowed) -- synchronises."""
+        counts, ov = self.eng.let_counts(with_overflow=True)
+        t = torch.tensor([max(counts), int(ov)], dtype=torch.int64, device=self.lbounds.device)
+        if dist.is_initialized() and self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t[0].item()), bool(t[1].item())
+
+    def autotune(self, slack: float = 1.5, floor: int = 256) -> int:
+        """One bounds + build on the current state, then let_cap = slack x the largest LET (all ranks
+        agree through an all_reduce).  Returns the new let_cap."""
+        self._exchange_bounds()
+        self.eng.let_build()
+        mx, _ = self.max_count()
+        cap = max(floor, (int(slack * mx) + 255) // 256 * 256)
+        if cap != self.let_cap:
+            self._configure(cap)
+        return cap
+
+    def check(self) -> int:
+        mx, ov = self.max_count()
+        if ov:
+            raise RuntimeError(f"a locally-essential tree outgrew let_cap={self.let_cap} (largest {mx}); "
+                               "results since the last check are invalid -- autotune() again")
+        return mx

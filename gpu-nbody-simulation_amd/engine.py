@@ -209,5 +209,40 @@ class BarnesHutEngine:
                                               C.byref(eb)))
         return p.value, v.value, m.value, n.value, eb.value
 
+    # -- distributed step with locally-essential trees ----------------------------------------
+    def let_configure(self, rank: int, world: int, let_cap: int) -> None:
+        self._check(self._lib.bh_let_configure(self._h, rank, world, let_cap))
+        self._let_world = world
+
+    def let_bounds(self) -> None:
+        self._check(self._lib.bh_let_bounds(self._h))
+
+    def let_pointers(self):
+        """(lbounds, all_bounds, send, recv, block_bytes) device pointers for the two collectives."""
+        a, b, s, r = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nb = C.c_int64()
+        self._check(self._lib.bh_let_pointers(self._h, C.byref(a), C.byref(b), C.byref(s), C.byref(r), C.byref(nb)))
+        return a.value, b.value, s.value, r.value, nb.value
+
+    def let_build(self) -> None:
+        self._check(self._lib.bh_let_build(self._h))
+
+    def let_walk(self) -> None:
+        self._check(self._lib.bh_let_walk(self._h))
+
+    def let_forces(self) -> None:
+        self._check(self._lib.bh_let_forces(self._h))
+
+    def let_counts(self, with_overflow: bool = False):
+        """Quads packed for each peer in the last let_build (waits for the stream).  Raises BhError(-4)
+        when a LET exceeded let_cap, unless with_overflow: then returns (counts, overflow flag)."""
+        arr = (C.c_uint32 * self._let_world)()
+        if with_overflow:
+            ov = C.c_int32()
+            self._check(self._lib.bh_let_counts(self._h, arr, C.byref(ov)))
+            return list(arr), bool(ov.value)
+        self._check(self._lib.bh_let_counts(self._h, arr, None))
+        return list(arr)
+
     def set_stream(self, hip_stream: int) -> None:
         self._check(self._lib.bh_set_stream(self._h, C.c_void_p(hip_stream)))

@@ -181,6 +181,32 @@ int bh_owned_range(bh_ctx *ctx, int64_t *lo, int64_t *hi);
 int bh_step_local(bh_ctx *ctx);
 int bh_device_sorted(bh_ctx *ctx, void **sorted_pos, void **sorted_vel);
 int bh_scatter_sorted(bh_ctx *ctx);
+/* Distributed step with locally-essential trees (LET).  Unlike the replicated scheme above, a
+ * context in LET mode holds ONLY ITS OWN bodies (bh_upload its subset).  Per step:
+ *   bh_let_bounds   -> raw min/max of the local bodies in a device buffer (4 doubles)
+ *   [host: all_gather the W x 4 doubles into the all_bounds buffer]
+ *   bh_let_build    -> global root box, local tree under it, and for every peer a compact LET
+ *                      (the quads that some body inside the peer's bounding box can open) packed
+ *                      in the send buffer, W fixed-size blocks of let_cap quads, child links
+ *                      already expressed in the receiver's index space
+ *   [host: all_to_all of the blocks, send buffer -> recv buffer]
+ *   bh_let_walk     -> every local body walks its own tree and the W-1 received LETs, integrate
+ * bh_let_pointers exposes the device buffers for the two collectives; block_bytes is the size of
+ * one per-peer block (the pointers change when let_cap does).  bh_let_counts waits for the stream and
+ * returns the LET sizes of the last build: with overflow == NULL it fails with BH_ERR_CAPACITY if one
+ * exceeded let_cap, otherwise it reports that in *overflow and returns BH_OK.  An overflowing LET is
+ * truncated safely (links past the block are cut), so the step completes but its forces are wrong:
+ * check the counts before trusting a run.  bh_let_configure may be called again with the same
+ * rank/world and a new let_cap (size the blocks from measured counts).  bh_let_forces =
+ * bh_let_walk without the integration.  fp32 mode only. */
+int bh_let_configure(bh_ctx *ctx, int32_t rank, int32_t world, int64_t let_cap);
+int bh_let_bounds(bh_ctx *ctx);
+int bh_let_pointers(bh_ctx *ctx, void **lbounds, void **all_bounds, void **send, void **recv,
+                    int64_t *block_bytes);
+int bh_let_build(bh_ctx *ctx);
+int bh_let_walk(bh_ctx *ctx);
+int bh_let_forces(bh_ctx *ctx);
+int bh_let_counts(bh_ctx *ctx, uint32_t *counts, int32_t *overflow);
 /* Run on an external HIP stream (e.g. torch's current stream), passed as void*. */
 int bh_set_stream(bh_ctx *ctx, void *hip_stream);
 

@@ -1,0 +1,131 @@
+"""Per-rank device time of the two multi-GPU decompositions, rehearsed on ONE GPU (no collectives):
+
+  replicated : every rank builds the whole tree, walks 1/W of the sorted bodies, scatters
+  LET        : every rank builds the tree of its n/W bodies, packs W-1 LETs, walks the forest
+
+W contexts stand in for W ranks; the exchange is done once by device copies, then each rank's
+chain (bounds -> build+pack -> forest walk, forces only so the state stays put) is enqueued K times
+back to back and timed.  What is missing relative to a real run is the two collectives
+(32 B x W all_gather, let_cap x 80 B x W all_to_all).
+
+  python scripts/let_emulate.py [--n 1048576] [--worlds 2,4,8] [--init plummer]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gpu_nbody_simulation_amd as G  # noqa: E402
+from gpu_nbody_simulation_amd import initial_conditions as IC  # noqa: E402
+from gpu_nbody_simulation_amd.distributed import partition_orb, wrap_device  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=1 << 20)
+    ap.add_argument("--worlds", default="2,4,8")
+    ap.add_argument("--init", default="plummer")
+    ap.add_argument("--reps", type=int, default=20)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    n = a.n
+    m, p, v = IC.make(a.init, n, 1, quasi_static=True)
+    cfg = dict(theta=0.5, max_depth=21, precision=G.Precision.F32, reference_compat=False)
+    res = {"n": n, "init": a.init, "rows": []}
+
+    with G.BarnesHutEngine(G.BhConfig(capacity=n, **cfg)) as e:
+        e.upload(p, v, m)
+        e.step(3); e.sync()
+        t0 = time.perf_counter(); e.step(a.reps); e.sync()
+        single = (time.perf_counter() - t0) / a.reps * 1e3
+    res["single_gpu_ms"] = single
+    print(f"N={n} {a.init}: single context {single:.3f} ms/step", flush=True)
+
+    for world in [int(x) for x in a.worlds.split(",")]:
+        # ---- replicated: rank 0's share (all shares are equal-sized; the densest is rank-dependent)
+        rep = []
+        with G.BarnesHutEngine(G.BhConfig(capacity=n, **cfg)) as e:
+            e.upload(p, v, m)
+            for r in sorted({0, world // 2, world - 1}):
+                # build + walk of the owned range, forces only (integrating without the all_gather
+                # would corrupt the other ranks' shares); each call ends in a host sync
+                e.set_owned_fraction(r, world)
+                for _ in range(3):
+                    e._check(e._lib.bh_compute_forces(e._h))
+                t0 = time.perf_counter()
+                for _ in range(a.reps):
+                    e._check(e._lib.bh_compute_forces(e._h))
+                rep.append((time.perf_counter() - t0) / a.reps * 1e3)
+        # ---- LET
+        parts = partition_orb(p, world)
+        cap_bodies = max(len(ix) for ix in parts)
+        engs, bufs = [], []
+
+        def wire(e):
+            lb, ab, sd, rv, nb = e.let_pointers()
+            return (wrap_device(lb, 4, "<f8", dev), wrap_device(ab, 4 * world, "<f8", dev),
+                    wrap_device(sd, world * nb, "|u1", dev), wrap_device(rv, world * nb, "|u1", dev), nb)
+
+        for r, ix in enumerate(parts):
+            e = G.BarnesHutEngine(G.BhConfig(capacity=cap_bodies, **cfg))
+            e.upload(p[ix], v[ix], m[ix])
+            e.let_configure(r, world, 1 << 16)
+            engs.append(e); bufs.append(wire(e))
+
+        def exchange_bounds():
+            for e in engs:
+                e.let_bounds(); e.sync()
+            allb = torch.cat([b[0] for b in bufs])
+            for b in bufs:
+                b[1].copy_(allb)
+            torch.cuda.synchronize()
+
+        def exchange_lets():
+            for r in range(world):
+                nb = bufs[r][4]
+                for q in range(world):
+                    if q != r:
+                        bufs[q][3][r * nb:(r + 1) * nb].copy_(bufs[r][2][q * nb:(q + 1) * nb])
+            torch.cuda.synchronize()
+
+        exchange_bounds()
+        for e in engs:
+            e.let_build(); e.sync()
+        counts = np.array([e.let_counts() for e in engs])
+        cap = max(256, (int(1.5 * counts.max()) + 255) // 256 * 256)
+        for i, e in enumerate(engs):
+            e.let_configure(i, world, cap); bufs[i] = wire(e)
+        exchange_bounds()
+        for e in engs:
+            e.let_build(); e.sync()
+        exchange_lets()
+        let = []
+        for e in engs:
+            for _ in range(3):
+                e.let_bounds(); e.let_build(); e.let_forces()
+            e.sync()
+            t0 = time.perf_counter()
+            for _ in range(a.reps):
+                e.let_bounds(); e.let_build(); e.let_forces()
+            e.sync()
+            let.append((time.perf_counter() - t0) / a.reps * 1e3)
+        for e in engs:
+            e.close()
+        row = {"world": world, "replicated_ms_max": max(rep), "let_ms_max": max(let), "let_ms_mean": float(np.mean(let)),
+               "let_quads_mean": float(counts[counts > 0].mean()), "let_quads_max": int(counts.max()),
+               "let_cap": cap, "all_to_all_bytes_per_rank": cap * 80 * (world - 1),
+               "bodies_per_rank": cap_bodies}
+        res["rows"].append(row)
+        print(json.dumps(row), flush=True)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/let_emulate_{a.init}_{n}.json", "w") as fh:
+        json.dump(res, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -81,3 +81,94 @@ class OracleStandInEngine:
 
     def download(self):
         return self.pos.astype(np.float64), self.vel.astype(np.float64)
+
+
+class LetStandInEngine:
+    """Stand-in for the bh_let_* surface of BarnesHutEngine (CPU tests of distributed.LetStepper).
+
+    Its "locally-essential tree" for every peer is simply ALL of its bodies (the theta -> 0 LET),
+    written into the fixed-size block for that peer behind a header {sender, destination, count};
+    the walk is the oracle's direct sum over own + received bodies.  What this exercises is the
+    orchestration: the all_gather of bounds, the block routing of the all_to_all, autotune and the
+    overflow check.  The device-side LET logic is covered by tests/test_gpu_let.py."""
+    QUAD_BYTES = 80
+
+    def __init__(self, G=6.67e-11, dt=1.0):
+        self.G, self.dt = G, dt
+
+    def upload(self, pos, vel, mass):
+        self.pos = np.array(pos, dtype=np.float32).reshape(-1, 2)
+        self.vel = np.array(vel, dtype=np.float32).reshape(-1, 2)
+        self.mass = np.array(mass, dtype=np.float32).reshape(-1)
+        self.n = len(self.mass)
+
+    def download(self):
+        return self.pos.astype(np.float64), self.vel.astype(np.float64)
+
+    def let_configure(self, rank, world, let_cap):
+        self.rank, self.world, self.let_cap = rank, world, let_cap
+        nb = let_cap * self.QUAD_BYTES
+        self.lbounds = torch.zeros(4, dtype=torch.float64)
+        self.all_bounds = torch.zeros(4 * world, dtype=torch.float64)
+        self.send = torch.zeros(world * nb, dtype=torch.uint8)
+        self.recv = torch.zeros(world * nb, dtype=torch.uint8)
+        self.counts, self.overflow = [0] * world, False
+
+    def let_pointers(self):
+        return self.lbounds, self.all_bounds, self.send, self.recv, self.let_cap * self.QUAD_BYTES
+
+    def let_bounds(self):
+        if self.n:
+            b = [self.pos[:, 0].min(), self.pos[:, 0].max(), self.pos[:, 1].min(), self.pos[:, 1].max()]
+        else:
+            b = [np.inf, -np.inf, np.inf, -np.inf]
+        self.lbounds[:] = torch.tensor(b, dtype=torch.float64)
+
+    def let_build(self):
+        nb = self.let_cap * self.QUAD_BYTES
+        self.seen_bounds = self.all_bounds.numpy().reshape(self.world, 4).copy()
+        rec = np.concatenate([self.pos, self.mass[:, None]], axis=1).astype(np.float32).reshape(-1)
+        need = 12 + rec.nbytes
+        quads = (need + self.QUAD_BYTES - 1) // self.QUAD_BYTES
+        self.overflow = quads > self.let_cap
+        send = self.send.numpy()
+        for q in range(self.world):
+            self.counts[q] = 0 if q == self.rank else quads
+            blk = send[q * nb:(q + 1) * nb]
+            blk[:] = 0
+            cnt = 0 if (self.overflow or q == self.rank) else self.n
+            blk[:12] = np.array([self.rank, q, cnt], dtype=np.int32).view(np.uint8)
+            blk[12:12 + 12 * cnt] = rec[:3 * cnt].view(np.uint8)
+
+    def let_counts(self, with_overflow=False):
+        if with_overflow:
+            return list(self.counts), self.overflow
+        if self.overflow:
+            raise RuntimeError("overflow")
+        return list(self.counts)
+
+    def _accel(self):
+        nb = self.let_cap * self.QUAD_BYTES
+        recv = self.recv.numpy()
+        ps, ms = [self.pos], [self.mass]
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            blk = recv[r * nb:(r + 1) * nb]
+            sender, dest, cnt = blk[:12].view(np.int32)
+            assert (sender, dest) == (r, self.rank), f"block {r} of rank {self.rank} came from {sender} for {dest}"
+            rec = blk[12:12 + 12 * cnt].view(np.float32).reshape(cnt, 3)
+            ps.append(rec[:, :2])
+            ms.append(rec[:, 2])
+        p = np.concatenate(ps).astype(np.float64)
+        m = np.concatenate(ms).astype(np.float64)
+        f = O.direct_forces(p, m, G=self.G)
+        return (f[:self.n] / m[:self.n, None]) if self.n else np.zeros((0, 2))
+
+    def let_forces(self):
+        self.acc = self._accel()
+
+    def let_walk(self):
+        a = self._accel()
+        self.vel = self.vel + (a * self.dt).astype(np.float32)
+        self.pos = self.pos + self.vel * np.float32(self.dt)

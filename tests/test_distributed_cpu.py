@@ -85,3 +85,88 @@ def test_world_one_uses_plain_step():
     assert (st.lo, st.hi) == (0, 32)
     st.step()
     assert not np.array_equal(eng.download()[0], p.astype(np.float64))
+
+
+# ---- LetStepper: all_gather of bounds + all_to_all of fixed-size LET blocks --------------------------
+def _let_worker(rank, world, port, n, steps, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_standin import LetStandInEngine
+    from gpu_nbody_simulation_amd.distributed import LetStepper, partition_orb
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, p, v = _inputs(n)
+    mine = partition_orb(p, world)[rank]
+    eng = LetStandInEngine()
+    eng.upload(p[mine], v[mine], m[mine])
+    st = LetStepper(eng, rank, world, let_cap=2, device=torch.device("cpu"))   # far too small on purpose
+    st.step(integrate=False)
+    overflowed = False
+    try:
+        st.check()
+    except RuntimeError:
+        overflowed = True
+    cap = st.autotune()
+    for _ in range(steps):
+        st.step()
+    largest = st.check()
+    pos, vel = eng.download()
+    np.savez(os.path.join(out_dir, f"let{rank}.npz"), pos=pos, vel=vel, idx=mine, cap=cap, largest=largest,
+             overflowed=overflowed, bounds=eng.seen_bounds)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 300), (3, 200)])
+def test_let_stepper_ranks_reproduce_the_direct_sum(tmp_path, world, n):
+    steps = 2
+    port = _free_port()
+    mp.spawn(_let_worker, args=(world, port, n, steps, str(tmp_path)), nprocs=world, join=True)
+    from oracle import bh_oracle as O
+    m, p, v = _inputs(n)
+    p64, v64, m64 = p.astype(np.float64), v.astype(np.float64), m.astype(np.float64)
+    pos, vel = p.copy(), v.copy()
+    for _ in range(steps):                                 # single-process fp32 state, fp64 direct sum
+        a = O.direct_forces(pos.astype(np.float64), m64) / m64[:, None]
+        vel = vel + a.astype(np.float32)
+        pos = pos + vel
+    got_p, got_v = np.zeros((n, 2)), np.zeros((n, 2))
+    seen = np.zeros(n, dtype=int)
+    caps = set()
+    for r in range(world):
+        d = np.load(tmp_path / f"let{r}.npz")
+        got_p[d["idx"]], got_v[d["idx"]] = d["pos"], d["vel"]
+        seen[d["idx"]] += 1
+        caps.add(int(d["cap"]))
+        assert bool(d["overflowed"])                       # let_cap=2 was reported as too small ...
+        assert int(d["largest"]) <= int(d["cap"])          # ... and autotune fixed it
+        # every rank saw every rank's bounds, in rank order
+        b = d["bounds"]
+        assert b.shape == (world, 4) and np.isfinite(b).all() and (b[:, 0] <= b[:, 1]).all()
+        if r:
+            assert np.array_equal(b, first_bounds)
+        first_bounds = b
+    assert (seen == 1).all()                               # the partition covers every body once
+    assert len(caps) == 1                                  # all ranks agreed on the new block size
+    np.testing.assert_allclose(got_v, vel.astype(np.float64), rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(got_p, pos.astype(np.float64), rtol=2e-6, atol=1e-9)
+    assert not np.array_equal(got_p, p64)
+
+
+def test_partition_orb_is_a_balanced_partition_into_disjoint_boxes():
+    from gpu_nbody_simulation_amd.distributed import partition_orb
+    rng = np.random.default_rng(0)
+    p = rng.normal(size=(1000, 2))
+    for world in (1, 2, 3, 5, 8):
+        parts = partition_orb(p, world)
+        allidx = np.sort(np.concatenate(parts))
+        assert np.array_equal(allidx, np.arange(1000))
+        sizes = [len(x) for x in parts]
+        assert max(sizes) - min(sizes) <= world
+        boxes = [(p[ix].min(0), p[ix].max(0)) for ix in parts]
+        for i in range(world):
+            for j in range(i + 1, world):
+                (alo, ahi), (blo, bhi) = boxes[i], boxes[j]
+                overlap = np.all(np.minimum(ahi, bhi) - np.maximum(alo, blo) > 0)
+                assert not overlap
