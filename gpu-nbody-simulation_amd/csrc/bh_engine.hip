@@ -44,7 +44,7 @@ struct bh_ctx {
     bool uploaded = false, tree_valid = false;
     int64_t internal_cap = 0, node_cap = 0;
     int sort_passes = 0;
-    int walk_mode = 0; bool walk_xcd = false;
+    int walk_mode = 0; bool walk_xcd = false; int walk_split = 0;   // 0 = automatic
     bool hilbert = false;                // fp32 mode: Hilbert-ordered keys (BH_HILBERT=0 disables, A/B)  // BH_WALK_PIPE / BH_WALK_XCD override (A/B)
     int partial_count = 0;         // > 0: partial[] holds per-workgroup min/max of the current positions
 
@@ -268,6 +268,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted)
     // a full-range integrating walk also leaves the min/max of the NEW positions per workgroup
     const bool want_partial = integrate && !to_sorted && lo == 0 && hi == c->n;
     double *partial = want_partial ? c->partial : nullptr;
+    int per_partial = kBlock;
     if (c->exact) {
         const unsigned grid = blocks_for(hi - lo, kBlock);
         auto args = [&](auto kern) {
@@ -291,9 +292,19 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted)
         a.forest_base = c->quads_local; a.let_cap = c->let_cap;
         // the register-lane stack holds 64 entries; the walk never needs more than 3*Dm + 2
         const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0 || (3 * c->Dm + 2 > kWave);
-        BH_HIP(c, launch_walk_fast(a, lds, stats, c->let_mode ? 0 : c->walk_mode, c->walk_xcd, c->stream));
+        const int mode = c->let_mode ? 0 : c->walk_mode;
+        // few bodies: several waves per 64-body group (bh_walk_fast.hip).  Measured best factor
+        // (scripts/split_sweep.py): 8 up to 32k bodies per launch, 4 up to 128k,
+        // one wave per group beyond.  BH_WALK_SPLIT overrides (1 = off).
+        int split = (c->cfg.flags & BH_FLAG_WALK_NO_SPLIT) ? 1 : c->walk_split;
+        if (split <= 0) {
+            const int64_t groups = (hi - lo + kWave - 1) / kWave;
+            split = groups <= 512 ? 8 : groups <= 2048 ? 4 : 1;
+        }
+        BH_HIP(c, launch_walk_fast(a, lds, stats, mode, c->walk_xcd, split, c->stream));
+        if (walk_fast_split_effective(a, lds, mode, split)) per_partial = kWave;
     }
-    if (want_partial) c->partial_count = (int)blocks_for(hi - lo, kBlock);
+    if (want_partial) c->partial_count = (int)blocks_for(hi - lo, per_partial);
     return BH_OK;
 }
 
@@ -348,6 +359,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     c->sort_passes = (2 * c->Dm + kRadixBits - 1) / kRadixBits;
     if (const char *e = std::getenv("BH_WALK_PIPE")) c->walk_mode = std::atoi(e);
     if (const char *e = std::getenv("BH_WALK_XCD")) c->walk_xcd = std::atoi(e) != 0;
+    if (const char *e = std::getenv("BH_WALK_SPLIT")) c->walk_split = std::atoi(e);
     if (const char *e = std::getenv("BH_SORT_ONESWEEP")) c->sort_onesweep = std::atoi(e) != 0;
     c->hilbert = !c->exact;
     if (const char *e = std::getenv("BH_HILBERT")) c->hilbert = !c->exact && std::atoi(e) != 0;
@@ -385,7 +397,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
       A(&c->os_status, c->os_status_words); A(&c->os_ghist, kMaxPasses * kRadix); A(&c->os_counter, kMaxPasses);
       A(&c->os_err, 4); }
     A(&c->bsum_u32, blocks_for(cap + 1, kTile) + 8);
-    A(&c->partial, 4 * (std::max<size_t>(1024, blocks_for(cap, kBlock)) + 2)); A(&c->box, 4);
+    A(&c->partial, 4 * (std::max<size_t>(1024, blocks_for(cap, kWave)) + 2)); A(&c->box, 4);
     A(&c->ctr, 1);
     if (c->exact) {
         A(&c->gd, c->node_cap); A(&c->ld, c->node_cap);

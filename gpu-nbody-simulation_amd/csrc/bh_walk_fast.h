@@ -34,8 +34,15 @@ struct WalkFastArgs {
     int64_t forest_base, let_cap;
 };
 
-// mode: 0 = one stack entry per iteration, 1 = software-pipelined, 2 = two entries per iteration
-hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, int mode, bool xcd,
+// mode: 0 = one stack entry per iteration, 1 = software-pipelined, 2 = two entries per iteration.
+// split: 1 = one wave per 64 bodies; 2/4/8/16 = that many waves share each 64-body group (few bodies).
+// The launch writes one `partial` entry per workgroup: per 256 bodies, or per 64 when split > 1
+// (walk_fast_split_effective tells which applies).
+hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, int mode, bool xcd, int split,
                             hipStream_t st);
+inline bool walk_fast_split_effective(const WalkFastArgs &a, bool lds_stack, int mode, int split)
+{
+    return split > 1 && !lds_stack && mode == 0 && a.n_trees <= 56;
+}
 
 }  // namespace bh

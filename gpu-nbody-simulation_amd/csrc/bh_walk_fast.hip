@@ -24,6 +24,17 @@
 //     perm), or into the sorted arrays for the multi-GPU exchange; plus the per-workgroup min/max of
 //     the new positions for the next step's root box.
 //   * BH_WALK_PIPE / BH_WALK_XCD select measured-and-rejected loop variants.
+//   * SPLIT > 1 (few bodies: N <= 128k on one GPU, or one rank's share of a multi-GPU run).  The
+//     walk of a 64-body group is a dependent chain of ~200 quad visits; a lone wave spends ~370
+//     cycles waiting for each quad and ~1000 issuing its evaluation (measured with s_memtime),
+//     ~0.1 ms in all however empty the GPU is, while a SIMD with 16 resident waves retires a quad
+//     every ~270 cycles.  With few groups a workgroup of SPLIT waves therefore shares ONE group and
+//     walks the forest LEVEL-SYNCHRONOUSLY: the frontier (quads some lane opened) of the current
+//     level sits in LDS, every wave takes an equal contiguous chunk of it, evaluates it with the
+//     usual per-body MAC (pushes go to its register-lane stack), and the waves' pushes are
+//     concatenated in wave order into the next level's frontier.  Chunks, offsets and the final
+//     wave-order sum of the partial accelerations are all fixed by the data, so results are
+//     reproducible run to run (they differ from the one-wave walk by fp32 summation order only).
 #include "bh_prims.hpp"
 #include "bh_nodes.hpp"
 #include "bh_bounds.hpp"
@@ -64,6 +75,8 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
 }
 
 constexpr int kLdsStackDepth = 128;   // 3*31+4 entries worst case
+constexpr int kSplitFrontier = 512;   // split walk: frontier entries per level kept in LDS (12 B each, x2)
+constexpr int kSplitRound = 16;       // split walk: quads per wave per round (4 pushes each fill the 64-lane stack)
 
 // Per child: one v_cmp decides accept/open/self (see eval); lane masks stay in SGPR pairs; the
 // three-register stack write happens only for nodes that some lane opens (uniform branches).
@@ -73,11 +86,17 @@ constexpr int kLdsStackDepth = 128;   // 3*31+4 entries worst case
 // a load latency only when an evaluation starts from an empty stack.  (fp32 mode does not need
 // the reference's visiting order, so taking an entry off the stack before the current quad has
 // pushed its children is allowed.)
-template <bool LDS_STACK, bool STATS, int MODE>
-__global__ __launch_bounds__(kBlock) void walk_fast_kernel(WalkFastArgs a)
+template <bool LDS_STACK, bool STATS, int MODE, int SPLIT>
+__global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_kernel(WalkFastArgs a)
 {
+    static_assert(SPLIT == 1 || (!LDS_STACK && MODE == 0), "the split walk uses the register-lane stack, loop 0");
     __shared__ int32_t s_base[LDS_STACK ? kWavesPerBlock : 1][LDS_STACK ? kLdsStackDepth : 1];
     __shared__ uint64_t s_mask[LDS_STACK ? kWavesPerBlock : 1][LDS_STACK ? kLdsStackDepth : 1];
+    // split walk: two frontiers (current / next level), the waves' push counts, the partial sums
+    constexpr int FCAP = SPLIT > 1 ? kSplitFrontier : 1;
+    __shared__ int32_t fr_base[2][FCAP], fr_lo[2][FCAP], fr_hi[2][FCAP];
+    __shared__ int32_t f_cnt[SPLIT > 1 ? SPLIT : 1];
+    __shared__ float2 f_red[SPLIT > 1 ? SPLIT : 1][SPLIT > 1 ? kWave : 1];
 
     if (a.ctr->overflow) return;
     // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each
@@ -87,8 +106,9 @@ __global__ __launch_bounds__(kBlock) void walk_fast_kernel(WalkFastArgs a)
     const uint32_t lb = a.xcd_chunk ? (blockIdx.x & 7u) * a.xcd_chunk + (blockIdx.x >> 3) : blockIdx.x;
     if (lb >= a.nblocks) return;
     const int lane = lane_id(), w = wave_id();
-    const int64_t s = a.lo + (int64_t)lb * kBlock + threadIdx.x;
-    const bool valid = s < a.hi;
+    // SPLIT > 1: every wave of the workgroup holds the SAME 64 bodies
+    const int64_t s = SPLIT > 1 ? a.lo + (int64_t)lb * kWave + lane : a.lo + (int64_t)lb * kBlock + threadIdx.x;
+    bool valid = s < a.hi;
     const float2 p = valid ? a.spos[s] : float2{0.f, 0.f};
     asm volatile("" ::"v"(p.x), "v"(p.y));                // take the one-time vmcnt wait here, not per child
     float ax = 0.f, ay = 0.f;
@@ -190,7 +210,104 @@ __global__ __launch_bounds__(kBlock) void walk_fast_kernel(WalkFastArgs a)
         return false;
     };
 
-    if (MODE == 1) {
+    if (SPLIT > 1) {
+        const uint64_t everyone = __ballot(valid);
+        // level 0: the root quad of the local tree and of every received LET (at most 57 entries)
+        int F = 1 + ((a.n_trees > 0) ? a.n_trees - 1 : 0);
+        if (w == 0 && lane < F) {
+            int32_t base = 0;
+            if (lane > 0) {
+                int32_t t = lane - 1;
+                if (t >= a.self_rank) ++t;                      // the peers in rank order, self skipped
+                base = (int32_t)(a.forest_base + (int64_t)t * a.let_cap);
+            }
+            fr_base[0][lane] = base;
+            fr_lo[0][lane] = (int32_t)(uint32_t)everyone;
+            fr_hi[0][lane] = (int32_t)(uint32_t)(everyone >> 32);
+        }
+        __syncthreads();
+        auto lane_entry = [&](int32_t vb, int32_t vl, int32_t vh, int j, int32_t &base, uint64_t &mask) {
+            base = __builtin_amdgcn_readlane(vb, j);
+            mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(vh, j) << 32) |
+                   (uint32_t)__builtin_amdgcn_readlane(vl, j);
+        };
+        int cur = 0;
+        while (F > 0) {                                         // one iteration per tree level
+            int produced = 0;
+            for (int r0 = 0; r0 < F; r0 += SPLIT * kSplitRound) {
+                const int rem = (F - r0 < SPLIT * kSplitRound) ? F - r0 : SPLIT * kSplitRound;
+                const int chunk = (rem + SPLIT - 1) / SPLIT;    // equal contiguous chunks, <= kSplitRound
+                const int first = r0 + w * chunk;
+                int mine = r0 + rem - first;
+                mine = (mine < 0) ? 0 : (mine > chunk ? chunk : mine);
+                int32_t in_base = 0, in_lo = 0, in_hi = 0;      // lane j holds this wave's j-th entry
+                if (lane < mine) {
+                    in_base = fr_base[cur][first + lane]; in_lo = fr_lo[cur][first + lane]; in_hi = fr_hi[cur][first + lane];
+                }
+                sp = 0;
+                // All of this wave's quads are known before the first is evaluated, so the scalar loads
+                // of entry j+1 are issued before entry j is evaluated (~1000 cycles for a lone wave against
+                // a ~370-cycle load): the depth-first loop cannot do this, its next address is the
+                // result of the evaluation.  (Bucket references and lanes past `mine` read quad 0.)
+                auto quad_of = [&](int j) {
+                    const int32_t b = __builtin_amdgcn_readlane(in_base, j & (kWave - 1));
+                    return load_quad(quads + (b < 0 ? 0 : b));
+                };
+                QuadRegs qn = quad_of(0);
+                for (int j = 0; j < mine; ++j) {
+                    int32_t base; uint64_t mask;
+                    lane_entry(in_base, in_lo, in_hi, j, base, mask);
+                    const QuadRegs q = qn;
+                    qn = quad_of(j + 1);
+                    if (base <= -2) { bucket(-base - 2, mask); continue; }
+                    if (base < 0) continue;
+                    eval_quad(q, mask);                         // opened children -> private stack, sp <= 64
+                }
+                if (lane == 0) f_cnt[w] = sp;
+                __syncthreads();
+                int off = produced, total = 0;
+#pragma unroll
+                for (int k = 0; k < SPLIT; ++k) {
+                    const int ck = __builtin_amdgcn_readfirstlane(f_cnt[k]);
+                    off += (k < w) ? ck : 0;
+                    total += ck;
+                }
+                if (produced + total <= FCAP) {                 // uniform over the workgroup
+                    if (lane < sp) {
+                        fr_base[cur ^ 1][off + lane] = v_base; fr_lo[cur ^ 1][off + lane] = v_lo; fr_hi[cur ^ 1][off + lane] = v_hi;
+                    }
+                    produced += total;
+                } else {
+                    // next frontier full (never seen in practice): every wave finishes the subtrees it
+                    // has just opened depth-first, one at a time so the 64-entry stack bound holds
+                    in_base = v_base; in_lo = v_lo; in_hi = v_hi;
+                    const int todo = sp;
+                    for (int j = 0; j < todo; ++j) {
+                        int32_t base; uint64_t mask;
+                        lane_entry(in_base, in_lo, in_hi, j, base, mask);
+                        sp = 0;
+                        if (base <= -2) { bucket(-base - 2, mask); continue; }
+                        if (base < 0) continue;
+                        do {
+                            const QuadRegs q = load_quad(quads + base);
+                            eval_quad(q, mask);
+                        } while (pop_quad(base, mask));
+                    }
+                }
+                __syncthreads();
+            }
+            cur ^= 1;
+            F = produced;
+        }
+        // ---- partial sums back to wave 0, added in wave order
+        f_red[w][lane] = float2{ax, ay};
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int k = 1; k < SPLIT; ++k) { ax += f_red[k][lane].x; ay += f_red[k][lane].y; }
+        }
+        valid = valid && (w == 0);
+    } else if (MODE == 1) {
         int32_t baseA = 0, baseB = 0;
         uint64_t maskA = __ballot(valid), maskB = 0;
         QuadRegs A = load_quad(quads), B;                   // quad 0: the root in slot 0
@@ -266,7 +383,16 @@ __global__ __launch_bounds__(kBlock) void walk_fast_kernel(WalkFastArgs a)
         }
     }
     // min/max of the new positions per workgroup: the next step's root box needs no body pass
-    if (a.partial) block_bounds_to_partial(valid, (double)np.x, (double)np.y, a.partial + 4 * (size_t)lb);
+    if (SPLIT > 1) {
+        if (a.partial && w == 0) {                          // one partial per 64-body group
+            const double xlo = wave_min(valid ? (double)np.x : (double)INFINITY), xhi = wave_max(valid ? (double)np.x : -(double)INFINITY);
+            const double ylo = wave_min(valid ? (double)np.y : (double)INFINITY), yhi = wave_max(valid ? (double)np.y : -(double)INFINITY);
+            if (lane == 0) {
+                double *o = a.partial + 4 * (size_t)lb;
+                o[0] = xlo; o[1] = xhi; o[2] = ylo; o[3] = yhi;
+            }
+        }
+    } else if (a.partial) block_bounds_to_partial(valid, (double)np.x, (double)np.y, a.partial + 4 * (size_t)lb);
     if (STATS && lane == 0) {
         atomicAdd(&a.ctr->visits, n_vis);
         atomicAdd(&a.ctr->interactions, n_int);
@@ -274,15 +400,16 @@ __global__ __launch_bounds__(kBlock) void walk_fast_kernel(WalkFastArgs a)
     }
 }
 
-template <bool L, bool S, int M>
+template <bool L, bool S, int M, int SPLIT = 1>
 static hipError_t launch(WalkFastArgs a, bool xcd, hipStream_t st)
 {
     const int64_t cnt = a.hi - a.lo;
     if (cnt <= 0) return hipSuccess;
-    a.nblocks = (uint32_t)((cnt + kBlock - 1) / kBlock);
+    constexpr int per_group = SPLIT > 1 ? kWave : kBlock;
+    a.nblocks = (uint32_t)((cnt + per_group - 1) / per_group);
     a.xcd_chunk = xcd ? (a.nblocks + 7) / 8 : 0;
     const unsigned grid = xcd ? 8 * a.xcd_chunk : a.nblocks;
-    hipLaunchKernelGGL((walk_fast_kernel<L, S, M>), dim3(grid), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL((walk_fast_kernel<L, S, M, SPLIT>), dim3(grid), dim3(SPLIT > 1 ? kWave * SPLIT : kBlock), 0, st, a);
     return hipGetLastError();
 }
 
@@ -296,9 +423,23 @@ static hipError_t launch_mode(const WalkFastArgs &a, int mode, bool xcd, hipStre
     }
 }
 
-hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, int mode, bool xcd,
+template <bool S>
+static hipError_t launch_split(const WalkFastArgs &a, int split, bool xcd, hipStream_t st)
+{
+    switch (split) {
+    case 2: return launch<false, S, 0, 2>(a, xcd, st);
+    case 4: return launch<false, S, 0, 4>(a, xcd, st);
+    case 8: return launch<false, S, 0, 8>(a, xcd, st);
+    default: return launch<false, S, 0, 16>(a, xcd, st);
+    }
+}
+
+hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, int mode, bool xcd, int split,
                             hipStream_t st)
 {
+    // the split walk exists for the register-lane stack and loop 0 only; its queue holds 56 roots
+    if (split > 1 && !lds_stack && mode == 0 && a.n_trees <= 56)
+        return stats ? launch_split<true>(a, split, xcd, st) : launch_split<false>(a, split, xcd, st);
     if (lds_stack) return stats ? launch_mode<true, true>(a, mode, xcd, st) : launch_mode<true, false>(a, mode, xcd, st);
     return stats ? launch_mode<false, true>(a, mode, xcd, st) : launch_mode<false, false>(a, mode, xcd, st);
 }

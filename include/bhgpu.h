@@ -51,6 +51,14 @@ typedef enum bh_precision {
 #define BH_FLAG_WALK_STATS   (1u << 0)  /* count visits/interactions in the walk (slower)   */
 #define BH_FLAG_LDS_STACK    (1u << 1)  /* fp32 walk: LDS traversal stack instead of the
                                            register-lane stack (A/B switch)  */
+#define BH_FLAG_WALK_NO_SPLIT (1u << 2) /* fp32 walk: always one wavefront per 64 bodies.  By
+                                           default a launch of few bodies (<= 128k: small N, or
+                                           one rank's share) lets 4 or 8 wavefronts share each
+                                           64-body group, level by level; same nodes, same
+                                           per-body criterion, but another order of the fp32
+                                           sums, so a body's last bits then depend on how many
+                                           bodies its launch walks (still reproducible run to
+                                           run).  Set this to rule that out.                 */
 
 /* Replaces the compile-time configuration of project.cu:1-11, 27-35, 60-62. */
 typedef struct bh_config {

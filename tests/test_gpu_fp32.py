@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 from oracle import bh_oracle as O  # noqa: E402
 import gpu_nbody_simulation_amd as G  # noqa: E402
 from gpu_nbody_simulation_amd import initial_conditions as IC  # noqa: E402
-from gpu_nbody_simulation_amd.engine import FLAG_LDS_STACK, FLAG_WALK_STATS  # noqa: E402
+from gpu_nbody_simulation_amd.engine import FLAG_LDS_STACK, FLAG_WALK_NO_SPLIT, FLAG_WALK_STATS  # noqa: E402
 
 TOL_MEDIAN, TOL_P999, TOL_MAX = 2e-6, 1e-4, 5e-3
 
@@ -77,7 +77,8 @@ def test_lds_and_register_stacks_agree_bitwise(gold):
     g = gold("ref_project_40960")
     m, p, v = f32(g["mass"]), f32(g["pos"]), f32(g["vel"])
     out = []
-    for flags in (0, FLAG_LDS_STACK):
+    # (one wavefront per 64 bodies on both sides: the split walk exists for the register stack only)
+    for flags in (FLAG_WALK_NO_SPLIT, FLAG_LDS_STACK):
         with engine(40960, max_depth=16, flags=flags) as e:
             e.upload(p, v, m)
             e.step(3)
@@ -237,3 +238,42 @@ def test_degenerate_input_stays_bounded():
         e.sync()
         assert time.time() - t0 < 5.0
         assert e.stats().n_nodes <= 1 + 4 * 21
+
+
+@pytest.mark.parametrize("split", [2, 4, 8, 16, 0])
+@pytest.mark.parametrize("kind,n,md", [("plummer", 65536, 21), ("clumped", 30000, 8)])
+def test_split_walk_equals_the_one_wave_walk(monkeypatch, split, kind, n, md):
+    """Several wavefronts per 64-body group (launches of few bodies; BH_WALK_SPLIT forces the factor,
+    0 = the automatic choice): same node set, same per-body MAC, only the order of the fp32 sums
+    changes -> identical interaction counts, accelerations equal to summation rounding, and the
+    per-group min/max left for the next step's root box are exact."""
+    if kind == "clumped":                                     # shallow cap: multi-body bucket leaves
+        rng = np.random.default_rng(5)
+        p = f32(np.concatenate([rng.normal(0, 1e-3, (n // 2, 2)), rng.uniform(-1, 1, (n - n // 2, 2))]))
+        m, v = f32(rng.uniform(0.1, 0.5, n)), f32(rng.uniform(-1e-9, 1e-9, (n, 2)))
+    else:
+        m, p, v = IC.make(kind, n, 3)
+        m, p, v = f32(m), f32(p), f32(v)
+    res = []
+    for sp, flags in ((1, FLAG_WALK_NO_SPLIT), (split, 0)):
+        monkeypatch.setenv("BH_WALK_SPLIT", str(sp))
+        with engine(n, max_depth=md, reference_compat=False, flags=flags | FLAG_WALK_STATS) as e:
+            e.upload(p, v, m)
+            e.compute_forces()
+            a = e.accelerations()
+            st = e.stats()
+            e.step(2)
+            pos, _ = e.download()
+            e.build_tree()                                     # root box from the walk's partials
+            root = e.export_tree()[0][0]
+        res.append((a, st, pos, root))
+    (a1, s1, p1, r1), (a2, s2, p2, r2) = res
+    assert (s1.interactions, s1.visits) == (s2.interactions, s2.visits)
+    r = rel_err(a2, a1)
+    assert np.median(r) < 5e-7 and r.max() < 1e-4
+    assert not np.array_equal(a1, a2) or split == 0           # the split really ran (auto may pick 1)
+    for pos, root in ((p1, r1), (p2, r2)):
+        ex = max(np.ptp(pos[:, 0]), np.ptp(pos[:, 1]))
+        np.testing.assert_allclose([root["xmin"], root["xmax"], root["ymin"], root["ymax"]],
+                                   [pos[:, 0].min() - 0.1 * ex, pos[:, 0].max() + 0.1 * ex,
+                                    pos[:, 1].min() - 0.1 * ex, pos[:, 1].max() + 0.1 * ex], rtol=1e-6)
