@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--theta", type=float, default=0.5)
     ap.add_argument("--max-depth", type=int, default=21)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--precision", choices=["f32", "mixed"], default="f32",
+                    help="f32: fp32 state and forces (the headline configuration); mixed: fp64 state, fp32 "
+                         "forces (BASELINE config 'fp64 positions / fp32 forces')")
     ap.add_argument("--lds-stack", action="store_true", help="A/B: LDS traversal stack variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second distribution")
@@ -127,9 +130,12 @@ def main():
     dev = torch.device("cuda", local)
 
     n = a.n_bodies
+    prec = G.Precision.MIXED if a.precision == "mixed" else G.Precision.F32
+    if prec == G.Precision.MIXED and a.decomposition == "replicated" and (a.gpus > 1 or a.force_sharded):
+        raise SystemExit("bench.py: --precision mixed runs on one GPU or with --decomposition let")
     mass, pos, vel = IC.make(a.init, n, a.seed, quasi_static=True)
     flags = FLAG_LDS_STACK if a.lds_stack else 0
-    cfg = G.BhConfig(capacity=n, theta=a.theta, max_depth=a.max_depth, precision=G.Precision.F32,
+    cfg = G.BhConfig(capacity=n, theta=a.theta, max_depth=a.max_depth, precision=prec,
                      reference_compat=False, device=local, flags=flags)
     sharded = world > 1 or a.force_sharded
     use_let = sharded and a.decomposition == "let"
@@ -138,7 +144,7 @@ def main():
         # every rank derives the same partition from the same synthetic state and keeps its part only
         mine = partition_orb(pos, world)[rank]
         cfg = G.BhConfig(capacity=max(len(mine), 1), theta=a.theta, max_depth=a.max_depth,
-                         precision=G.Precision.F32, reference_compat=False, device=local, flags=flags)
+                         precision=prec, reference_compat=False, device=local, flags=flags)
     eng = G.BarnesHutEngine(cfg)
     if sharded:
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -195,7 +201,7 @@ def main():
     out = None
     if rank == 0:
         with G.BarnesHutEngine(G.BhConfig(capacity=n, theta=a.theta, max_depth=a.max_depth,
-                                          precision=G.Precision.F32, reference_compat=False, device=local,
+                                          precision=prec, reference_compat=False, device=local,
                                           flags=flags | FLAG_WALK_STATS)) as se:
             se.upload(pf, vf, mass)
             se.compute_forces()
@@ -228,7 +234,8 @@ def main():
             "metric": "body-steps/sec", "value": value, "unit": "body-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if a.precision == "f32" else "f64 state / f32 forces", "data": "synthetic",
             "config": {"workload": f"{a.init}_N{n}_theta{a.theta}", "n_bodies": n, "theta": a.theta,
                        "max_depth": a.max_depth, "init": a.init, "seed": a.seed,
                        "parallelism": "1 GPU" if not sharded else

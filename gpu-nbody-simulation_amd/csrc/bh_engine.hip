@@ -44,6 +44,7 @@ struct bh_ctx {
     bool uploaded = false, tree_valid = false;
     int64_t internal_cap = 0, node_cap = 0;
     int sort_passes = 0;
+    bool state64 = false;          // fp64 state arrays: exact and mixed precision
     int walk_mode = 0; bool walk_xcd = false; int walk_split = 0;   // 0 = automatic
     bool hilbert = false;                // fp32 mode: Hilbert-ordered keys (BH_HILBERT=0 disables, A/B)  // BH_WALK_PIPE / BH_WALK_XCD override (A/B)
     int partial_count = 0;         // > 0: partial[] holds per-workgroup min/max of the current positions
@@ -150,11 +151,12 @@ void owned_range(const bh_ctx *c, int64_t *lo, int64_t *hi)
     *hi = std::min<int64_t>(c->n, chunk * (c->rank + 1));
 }
 
-template <bool EXACT>
+template <bool EXACT, bool STATE64 = EXACT>
 int enqueue_build_t(bh_ctx *c)
 {
-    using Real2 = typename std::conditional<EXACT, double2, float2>::type;
-    using Real = typename std::conditional<EXACT, double, float>::type;
+    static_assert(!EXACT || STATE64, "exact mode keeps its state in fp64");
+    using Real2 = typename std::conditional<STATE64, double2, float2>::type;   // the state
+    using Real = typename std::conditional<STATE64, double, float>::type;
     const int64_t n = c->n;
     const int Dm = c->Dm;
     hipStream_t st = c->stream;
@@ -215,9 +217,11 @@ int enqueue_build_t(bh_ctx *c)
         // 4. cells owned by each sorted neighbour pair (+ fp32: sorted copies and prefix-sum terms),
         // 5. their ranks / the prefix sums
         const unsigned nbs = blocks_for(n + 1, kTile);
-        hipLaunchKernelGGL((prep_kernel<EXACT, Real2, Real>), dim3(nbs), dim3(kBlock), 0, st, c->keys_sorted,
-                           c->perm, pos, mass, c->cnt, c->bsum_u32, (Real2 *)c->spos, (Real *)c->smass, c->terms,
-                           c->bsum_d3, c->coarse, n, Dm);
+        using SReal2 = typename std::conditional<EXACT, double2, float2>::type;    // what the walk reads
+        using SReal = typename std::conditional<EXACT, double, float>::type;
+        hipLaunchKernelGGL((prep_kernel<EXACT, Real2, Real, SReal2, SReal>), dim3(nbs), dim3(kBlock), 0, st,
+                           c->keys_sorted, c->perm, pos, mass, c->cnt, c->bsum_u32, (SReal2 *)c->spos,
+                           (SReal *)c->smass, c->terms, c->bsum_d3, c->coarse, n, Dm);
         hipLaunchKernelGGL(scan_top2, dim3(EXACT ? 1 : 2), dim3(kBlock), 0, st, c->bsum_u32, c->bsum_d3, (int)nbs,
                            c->ctr);
         hipLaunchKernelGGL((scan_apply2<EXACT>), dim3(nbs), dim3(kBlock), 0, st, c->cnt, c->bsum_u32, c->terms,
@@ -257,7 +261,11 @@ int enqueue_build_t(bh_ctx *c)
     return BH_OK;
 }
 
-int enqueue_build(bh_ctx *c) { return c->exact ? enqueue_build_t<true>(c) : enqueue_build_t<false>(c); }
+int enqueue_build(bh_ctx *c)
+{
+    if (c->exact) return enqueue_build_t<true>(c);
+    return c->state64 ? enqueue_build_t<false, true>(c) : enqueue_build_t<false, false>(c);
+}
 
 int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted)
 {
@@ -284,6 +292,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted)
         WalkFastArgs a{};
         a.quads = c->qf; a.aux = c->aux; a.partial = partial; a.spos = c->spos; a.smass = c->smass; a.perm = c->perm;
         a.pos = (float2 *)c->pos; a.vel = (float2 *)c->vel;
+        a.state64 = c->state64 ? 1 : 0;               // mixed precision: pos/vel point at double2 arrays
         a.spos_out = c->spos_out; a.svel = c->svel;
         a.acc_out = (float2 *)c->force; a.ctr = c->ctr;
         a.lo = lo; a.hi = hi; a.G = (float)c->cfg.G; a.dt = (float)c->cfg.dt;
@@ -325,7 +334,7 @@ int check_overflow(bh_ctx *c)
 }  // namespace
 
 // ================================================================================================
-static int download_pairs(bh_ctx *c, const void *dev, double *host, int64_t count);
+static int download_pairs(bh_ctx *c, const void *dev, double *host, int64_t count, bool is64);
 
 extern "C" {
 
@@ -342,7 +351,8 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     if (cfg->max_depth < 1 || cfg->max_depth > 32)
         return fail(nullptr, BH_ERR_ARG, "bh_create: max_depth must be 1..32");
     if (!(cfg->theta > 0.0)) return fail(nullptr, BH_ERR_ARG, "bh_create: theta must be > 0");
-    if (cfg->precision != BH_PRECISION_F64_EXACT && cfg->precision != BH_PRECISION_F32)
+    if (cfg->precision != BH_PRECISION_F64_EXACT && cfg->precision != BH_PRECISION_F32 &&
+        cfg->precision != BH_PRECISION_MIXED)
         return fail(nullptr, BH_ERR_ARG, "bh_create: unknown precision");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -354,6 +364,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     c->cfg = *cfg;
     c->Dm = cfg->max_depth - 1;
     c->exact = cfg->precision == BH_PRECISION_F64_EXACT;
+    c->state64 = c->exact || cfg->precision == BH_PRECISION_MIXED;
     c->compat = cfg->reference_compat != 0;
     c->device = cfg->device;
     c->sort_passes = (2 * c->Dm + kRadixBits - 1) / kRadixBits;
@@ -381,13 +392,13 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     }
     c->internal_cap = (c->node_cap - 1) / 4;
 
-    const size_t rs = c->exact ? sizeof(double) : sizeof(float);
+    const size_t rs = c->state64 ? sizeof(double) : sizeof(float);
     int rc = 0;
     auto A = [&](auto **pp, size_t count) { if (!rc) rc = dev_alloc(c, pp, count); };
     { char *t; A(&t, cap * 2 * rs); c->pos = t; }
     { char *t; A(&t, cap * 2 * rs); c->vel = t; }
     { char *t; A(&t, cap * rs); c->mass = t; }
-    { char *t; A(&t, cap * 2 * rs); c->force = t; }
+    { char *t; A(&t, cap * 2 * (c->exact ? sizeof(double) : sizeof(float))); c->force = t; }
     A(&c->keys[0], cap); A(&c->keys[1], cap); A(&c->vals[0], cap); A(&c->vals[1], cap);
     A(&c->cnt, cap + 1);
     { const size_t nbl = blocks_for(cap, kSortTile);
@@ -448,7 +459,7 @@ int bh_upload(bh_ctx *c, const double *pos, const double *vel, const double *mas
         return fail(c, BH_ERR_ARG, "Requested number of bodies exceeds N_BODIES.");   // project.cu:110-112
     BH_HIP(c, hipSetDevice(c->device));
     BH_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->exact) {
+    if (c->state64) {
         BH_HIP(c, hipMemcpy(c->pos, pos, n * 2 * sizeof(double), hipMemcpyHostToDevice));
         BH_HIP(c, hipMemcpy(c->vel, vel, n * 2 * sizeof(double), hipMemcpyHostToDevice));
         BH_HIP(c, hipMemcpy(c->mass, mass, n * sizeof(double), hipMemcpyHostToDevice));
@@ -470,9 +481,9 @@ int bh_upload(bh_ctx *c, const double *pos, const double *vel, const double *mas
     return BH_OK;
 }
 
-static int download_pairs(bh_ctx *c, const void *dev, double *host, int64_t count)
+static int download_pairs(bh_ctx *c, const void *dev, double *host, int64_t count, bool is64)
 {
-    if (c->exact) {
+    if (is64) {
         BH_HIP(c, hipMemcpy(host, dev, count * sizeof(double), hipMemcpyDeviceToHost));
     } else {
         std::vector<float> t(std::max<int64_t>(count, 1));
@@ -492,7 +503,7 @@ int bh_initialize(bh_ctx *c, int64_t n, uint64_t seed, int32_t kind, double lowe
     BH_HIP(c, hipSetDevice(c->device));
     if (n > 0) {
         const unsigned g = blocks_for(n, kBlock);
-        if (c->exact)
+        if (c->state64)
             hipLaunchKernelGGL((init_bodies_kernel<double2, double>), dim3(g), dim3(kBlock), 0, c->stream,
                                (double2 *)c->pos, (double2 *)c->vel, (double *)c->mass, n, seed, kind, lower_m,
                                higher_m, lower_p, higher_p, lower_v, higher_v);
@@ -517,7 +528,7 @@ int bh_download_masses(bh_ctx *c, double *mass)
     if (!c->uploaded) return fail(c, BH_ERR_STATE, "bh_download_masses before bh_upload/bh_initialize");
     BH_HIP(c, hipSetDevice(c->device));
     BH_HIP(c, hipStreamSynchronize(c->stream));
-    return download_pairs(c, c->mass, mass, c->n);
+    return download_pairs(c, c->mass, mass, c->n, c->state64);
 }
 
 int bh_sync(bh_ctx *c)
@@ -539,9 +550,9 @@ int bh_download(bh_ctx *c, double *pos, double *vel)
     int rc = c->tree_valid ? check_overflow(c) : BH_OK;
     if (rc) return rc;
     BH_HIP(c, hipStreamSynchronize(c->stream));
-    rc = download_pairs(c, c->pos, pos, 2 * c->n);
+    rc = download_pairs(c, c->pos, pos, 2 * c->n, c->state64);
     if (rc) return rc;
-    if (vel) rc = download_pairs(c, c->vel, vel, 2 * c->n);
+    if (vel) rc = download_pairs(c, c->vel, vel, 2 * c->n, c->state64);
     return rc;
 }
 
@@ -603,12 +614,13 @@ int bh_get_forces(bh_ctx *c, double *out)
     if (!c || !out) return fail(c, BH_ERR_ARG, "bh_get_forces: null array");
     BH_HIP(c, hipSetDevice(c->device));
     BH_HIP(c, hipStreamSynchronize(c->stream));
-    int rc = download_pairs(c, c->force, out, 2 * c->n);
+    int rc = download_pairs(c, c->force, out, 2 * c->n, c->exact);
     if (rc) return rc;
-    if (!c->exact) {   // fp32 mode stores accelerations; force = a * m_i
-        std::vector<float> m(std::max<int64_t>(c->n, 1));
-        BH_HIP(c, hipMemcpy(m.data(), c->mass, c->n * sizeof(float), hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < c->n; ++i) { out[2 * i] *= (double)m[i]; out[2 * i + 1] *= (double)m[i]; }
+    if (!c->exact) {   // fp32 / mixed mode store accelerations; force = a * m_i
+        std::vector<double> m(std::max<int64_t>(c->n, 1));
+        rc = download_pairs(c, c->mass, m.data(), c->n, c->state64);
+        if (rc) return rc;
+        for (int64_t i = 0; i < c->n; ++i) { out[2 * i] *= m[i]; out[2 * i + 1] *= m[i]; }
     }
     return BH_OK;
 }
@@ -618,7 +630,7 @@ int bh_get_accel(bh_ctx *c, double *out)
     if (!c || !out) return fail(c, BH_ERR_ARG, "bh_get_accel: null array");
     BH_HIP(c, hipSetDevice(c->device));
     BH_HIP(c, hipStreamSynchronize(c->stream));
-    int rc = download_pairs(c, c->force, out, 2 * c->n);
+    int rc = download_pairs(c, c->force, out, 2 * c->n, c->exact);
     if (rc) return rc;
     if (c->exact) {    // exact mode stores forces; a = F / m_i (updateAccelerations, project.cu:795-801)
         std::vector<double> m(std::max<int64_t>(c->n, 1));
@@ -728,7 +740,7 @@ int bh_write_quadtree_file(bh_ctx *c, const char *path)
     int rc = export_tree_host(c, out, dep);
     if (rc) return rc;
     std::vector<double> pos(std::max<int64_t>(2 * c->n, 2));
-    rc = download_pairs(c, c->pos, pos.data(), 2 * c->n);
+    rc = download_pairs(c, c->pos, pos.data(), 2 * c->n, c->state64);
     if (rc) return rc;
     FILE *fp = std::fopen(path, "w");
     if (!fp) return fail(c, BH_ERR_IO, std::string("cannot open ") + path);
@@ -806,14 +818,14 @@ int bh_device_state(bh_ctx *c, void **pos, void **vel, void **mass, int64_t *n, 
     if (vel) *vel = c->vel;
     if (mass) *mass = c->mass;
     if (n) *n = c->n;
-    if (elem_bytes) *elem_bytes = c->exact ? 8 : 4;
+    if (elem_bytes) *elem_bytes = c->state64 ? 8 : 4;
     return BH_OK;
 }
 
 int bh_device_sorted(bh_ctx *c, void **sorted_pos, void **sorted_vel)
 {
     if (!c) return BH_ERR_ARG;
-    if (c->exact) return fail(c, BH_ERR_STATE, "sorted exchange buffers exist in fp32 mode only");
+    if (c->state64) return fail(c, BH_ERR_STATE, "sorted exchange buffers exist in fp32 mode only");
     if (sorted_pos) *sorted_pos = c->spos_out;
     if (sorted_vel) *sorted_vel = c->svel;
     return BH_OK;
@@ -842,7 +854,7 @@ int bh_step_local(bh_ctx *c)
 {
     if (!c) return BH_ERR_ARG;
     if (!c->uploaded) return fail(c, BH_ERR_STATE, "bh_step_local before bh_upload");
-    if (c->exact) return fail(c, BH_ERR_STATE, "bh_step_local: fp32 mode only");
+    if (c->state64) return fail(c, BH_ERR_STATE, "bh_step_local: fp32 mode only");
     BH_HIP(c, hipSetDevice(c->device));
     int rc = enqueue_build(c);
     if (rc) return rc;
@@ -852,7 +864,7 @@ int bh_step_local(bh_ctx *c)
 int bh_scatter_sorted(bh_ctx *c)
 {
     if (!c) return BH_ERR_ARG;
-    if (c->exact) return fail(c, BH_ERR_STATE, "bh_scatter_sorted: fp32 mode only");
+    if (c->state64) return fail(c, BH_ERR_STATE, "bh_scatter_sorted: fp32 mode only");
     BH_HIP(c, hipSetDevice(c->device));
     if (c->n > 0) {
         hipLaunchKernelGGL(scatter_sorted_kernel, dim3(blocks_for(c->n, kBlock)), dim3(kBlock), 0, c->stream,
@@ -869,7 +881,7 @@ int bh_let_configure(bh_ctx *c, int32_t rank, int32_t world, int64_t let_cap)
 {
     if (!c || world < 1 || world > kMaxWorld || rank < 0 || rank >= world || let_cap < 1)
         return fail(c, BH_ERR_ARG, "bh_let_configure: bad rank/world/let_cap (world <= 64)");
-    if (c->exact) return fail(c, BH_ERR_STATE, "bh_let_configure: fp32 mode only");
+    if (c->exact) return fail(c, BH_ERR_STATE, "bh_let_configure: fp32 and mixed precision only");
     BH_HIP(c, hipSetDevice(c->device));
     BH_HIP(c, hipStreamSynchronize(c->stream));
     int rc = 0;
@@ -911,8 +923,12 @@ int bh_let_bounds(bh_ctx *c)
     BH_HIP(c, hipSetDevice(c->device));
     if (c->partial_count <= 0) {
         const unsigned nbb = std::max(1u, std::min(1024u, blocks_for(c->n, kBlock)));
-        hipLaunchKernelGGL((bounds_partial<float2>), dim3(nbb), dim3(kBlock), 0, c->stream, (const float2 *)c->pos,
-                           c->n, c->partial);
+        if (c->state64)
+            hipLaunchKernelGGL((bounds_partial<double2>), dim3(nbb), dim3(kBlock), 0, c->stream,
+                               (const double2 *)c->pos, c->n, c->partial);
+        else
+            hipLaunchKernelGGL((bounds_partial<float2>), dim3(nbb), dim3(kBlock), 0, c->stream,
+                               (const float2 *)c->pos, c->n, c->partial);
         c->partial_count = (int)nbb;
     }
     hipLaunchKernelGGL(let_local_bounds_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->partial, c->partial_count,

@@ -161,14 +161,15 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
 // One workgroup per scan tile (kTile consecutive sorted bodies); element k*256 + t belongs to
 // thread t, so every access is coalesced.  Also produces the tile sums of both scans, so no
 // separate reduction launches are needed.
-template <bool EXACT, typename Real2, typename Real>
+// (Real2/Real: the state's type; SReal2/SReal: the type of the sorted copies the walk reads)
+template <bool EXACT, typename Real2, typename Real, typename SReal2 = Real2, typename SReal = Real>
 __global__ __launch_bounds__(kBlock) void prep_kernel(const uint64_t *__restrict__ keys,
                                                        const uint32_t *__restrict__ perm,
                                                        const Real2 *__restrict__ pos,
                                                        const Real *__restrict__ mass,
                                                        uint32_t *__restrict__ cnt,
                                                        uint32_t *__restrict__ bsum_u32,
-                                                       Real2 *__restrict__ spos, Real *__restrict__ smass,
+                                                       SReal2 *__restrict__ spos, SReal *__restrict__ smass,
                                                        d3 *__restrict__ terms, d3 *__restrict__ bsum_d3,
                                                        uint64_t *__restrict__ coarse, int64_t n, int Dm)
 {
@@ -196,8 +197,8 @@ __global__ __launch_bounds__(kBlock) void prep_kernel(const uint64_t *__restrict
                 const uint32_t b = perm[i];
                 const Real2 p = pos[b];
                 const Real m = mass[b];
-                spos[i] = p;
-                smass[i] = m;
+                spos[i] = SReal2{static_cast<SReal>(p.x), static_cast<SReal>(p.y)};
+                smass[i] = static_cast<SReal>(m);
                 const d3 t{(double)m, (double)m * (double)p.x, (double)m * (double)p.y};
                 terms[i] = t;
                 tsum += t;

@@ -18,7 +18,9 @@ struct WalkFastArgs {
     const float2 *spos;        // positions in Morton-sorted order
     const float *smass;        // masses in sorted order (bucket leaves only)
     const uint32_t *perm;      // sorted index -> caller index
-    float2 *pos, *vel;         // caller-order state (updated when integrate && !to_sorted)
+    float2 *pos, *vel;         // caller-order state (updated when integrate && !to_sorted);
+                               // double2 arrays when state64 (mixed precision)
+    int32_t state64;
     float2 *spos_out, *svel;   // sorted-order outputs (integrate && to_sorted)
     float2 *acc_out;           // caller-order accelerations, may be null
     TreeCounters *ctr;

@@ -364,11 +364,23 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
     }
 
     float2 np = p;
+    double2 np64{0.0, 0.0};
     if (valid) {
         const float gx = a.G * ax, gy = a.G * ay;
         const uint32_t body = a.perm[s];
         if (a.acc_out) a.acc_out[body] = float2{gx, gy};
-        if (a.integrate) {
+        if (a.integrate && a.state64) {
+            // mixed precision: the fp32 acceleration advances the fp64 state (updateAccVelPos,
+            // project.cu:819-836, in the state's precision)
+            double2 *pos64 = reinterpret_cast<double2 *>(a.pos), *vel64 = reinterpret_cast<double2 *>(a.vel);
+            double2 v = vel64[body];
+            const double2 q = pos64[body];
+            v.x = fma((double)gx, (double)a.dt, v.x);
+            v.y = fma((double)gy, (double)a.dt, v.y);
+            np64 = double2{fma(v.x, (double)a.dt, q.x), fma(v.y, (double)a.dt, q.y)};
+            vel64[body] = v;
+            pos64[body] = np64;
+        } else if (a.integrate) {
             float2 v = a.vel[body];
             v.x = fmaf(gx, a.dt, v.x);
             v.y = fmaf(gy, a.dt, v.y);
@@ -383,16 +395,17 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
         }
     }
     // min/max of the new positions per workgroup: the next step's root box needs no body pass
+    const double bx = a.state64 ? np64.x : (double)np.x, by = a.state64 ? np64.y : (double)np.y;
     if (SPLIT > 1) {
         if (a.partial && w == 0) {                          // one partial per 64-body group
-            const double xlo = wave_min(valid ? (double)np.x : (double)INFINITY), xhi = wave_max(valid ? (double)np.x : -(double)INFINITY);
-            const double ylo = wave_min(valid ? (double)np.y : (double)INFINITY), yhi = wave_max(valid ? (double)np.y : -(double)INFINITY);
+            const double xlo = wave_min(valid ? bx : (double)INFINITY), xhi = wave_max(valid ? bx : -(double)INFINITY);
+            const double ylo = wave_min(valid ? by : (double)INFINITY), yhi = wave_max(valid ? by : -(double)INFINITY);
             if (lane == 0) {
                 double *o = a.partial + 4 * (size_t)lb;
                 o[0] = xlo; o[1] = xhi; o[2] = ylo; o[3] = yhi;
             }
         }
-    } else if (a.partial) block_bounds_to_partial(valid, (double)np.x, (double)np.y, a.partial + 4 * (size_t)lb);
+    } else if (a.partial) block_bounds_to_partial(valid, bx, by, a.partial + 4 * (size_t)lb);
     if (STATS && lane == 0) {
         atomicAdd(&a.ctr->visits, n_vis);
         atomicAdd(&a.ctr->interactions, n_int);

@@ -26,6 +26,7 @@ FLAG_WALK_NO_SPLIT = 1 << 2
 class Precision(enum.IntEnum):
     F64_EXACT = 0   # bit-identical to the reference CPU path
     F32 = 1         # throughput mode (BASELINE configs "fp32")
+    MIXED = 2       # fp64 state, fp32 forces (BASELINE config "fp64 positions / fp32 forces")
 
 
 class BhError(RuntimeError):

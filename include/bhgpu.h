@@ -44,7 +44,13 @@ typedef enum bh_precision {
      * results are bit-identical to the reference CPU path (project.cu:865-916). */
     BH_PRECISION_F64_EXACT = 0,
     /* fp32 state and arithmetic (BASELINE config "fp32"): the throughput mode. */
-    BH_PRECISION_F32 = 1
+    BH_PRECISION_F32 = 1,
+    /* fp64 state, fp32 forces (BASELINE config "fp64 positions / fp32 forces"): positions,
+     * velocities and masses are kept and integrated in fp64, the tree keys and the centres of mass
+     * are computed from the fp64 positions, the theta-walk runs in fp32 on rounded copies exactly
+     * as in BH_PRECISION_F32.  For runs where a step's displacement is below the fp32 resolution
+     * of the coordinates.  Single-GPU step and the LET distributed step; not the replicated one. */
+    BH_PRECISION_MIXED = 2
 } bh_precision;
 
 /* bh_config.flags */

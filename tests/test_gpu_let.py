@@ -29,7 +29,8 @@ class EmulatedRanks:
         self.engs, self.bufs = [], []
         cap = max(len(ix) for ix in self.parts)
         for r, ix in enumerate(self.parts):
-            e = G.BarnesHutEngine(G.BhConfig(capacity=cap, precision=G.Precision.F32, **cfg))
+            cfg.setdefault("precision", G.Precision.F32)
+            e = G.BarnesHutEngine(G.BhConfig(capacity=cap, **cfg))
             e.upload(pos[ix], vel[ix], mass[ix])
             e.let_configure(r, world, let_cap)
             lb, ab, sd, rv, nb = e.let_pointers()

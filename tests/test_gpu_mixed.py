@@ -1,0 +1,116 @@
+"""GPU parity, BH_PRECISION_MIXED (BASELINE config "fp64 positions / fp32 forces"): the state is kept
+and integrated in fp64, tree keys and centres of mass come from the fp64 positions, the theta-walk runs
+in fp32 on rounded copies.
+
+Stated tolerances, per body, against the fp64 oracle on the SAME fp64 inputs (not fp32-representable,
+so rounding the walk's copies is part of the error): relative acceleration error
+    median <= 5e-6 ; 99.9 % <= 5e-4 ; every body <= 2e-2
+(the oracle here is the uncapped tree + per-body MAC; the tail is MAC flips as in test_gpu_fp32.py).
+Displacements over k quasi-static steps (|dx| << fp32 resolution of x) track the oracle's fp64 run to
+1e-5 relative, where BH_PRECISION_F32 cannot move the bodies at all."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bh_oracle as O  # noqa: E402
+import gpu_nbody_simulation_amd as G  # noqa: E402
+from gpu_nbody_simulation_amd import initial_conditions as IC  # noqa: E402
+from test_gpu_let import EmulatedRanks, rel  # noqa: E402
+
+
+def engine(n, precision=G.Precision.MIXED, **kw):
+    kw.setdefault("max_depth", 21)
+    kw.setdefault("reference_compat", False)
+    return G.BarnesHutEngine(G.BhConfig(capacity=n, precision=precision, **kw))
+
+
+@pytest.mark.parametrize("kind,n", [("uniform", 40000), ("plummer", 65536)])
+def test_mixed_accelerations_and_tree(kind, n):
+    m, p, v = IC.make(kind, n, 5)
+    p = p * (1.0 + 3e-9 * np.random.default_rng(1).standard_normal(p.shape))   # not fp32-representable
+    assert not np.array_equal(p, p.astype(np.float32).astype(np.float64))
+    t = O.build_tree(p, m, 0)
+    ref = O.compute_forces(t, p, m, compat_self_skip=False) / m[:, None]
+    with engine(n) as e:
+        e.upload(p, v, m)
+        e.compute_forces()
+        a = e.accelerations()
+        f = e.forces()
+        nodes, depth = e.export_tree()
+        pd, vd = e.download()
+        md = e.masses()
+    # state is held in fp64: what went in comes back bit for bit
+    assert np.array_equal(pd, p) and np.array_equal(vd, v) and np.array_equal(md, m)
+    r = rel(a, ref)
+    assert np.median(r) <= 5e-6 and np.quantile(r, 0.999) <= 5e-4 and r.max() <= 2e-2
+    np.testing.assert_allclose(f, a * m[:, None], rtol=1e-12)
+    # the tree is the tree of the fp64 positions (keys are computed from them)
+    t21 = O.build_tree(p, m, 21)
+    assert len(nodes) == len(t21)
+    root = nodes[0]
+    lo, hi = p.min(0), p.max(0)
+    ex = max(hi - lo)
+    np.testing.assert_allclose([root["xmin"], root["xmax"], root["ymin"], root["ymax"]],
+                               [lo[0] - 0.1 * ex, hi[0] + 0.1 * ex, lo[1] - 0.1 * ex, hi[1] + 0.1 * ex], rtol=1e-14)
+    np.testing.assert_allclose(root["mass"], m.sum(), rtol=1e-6)
+
+
+def test_mixed_keeps_displacements_below_fp32_resolution():
+    n, steps = 20000, 5
+    m, p, v = IC.make("uniform", n, 8, quasi_static=True)   # |v| <= 1e-9 per step against |x| ~ 0.1
+    p = p * (1.0 + 3e-9 * np.random.default_rng(2).standard_normal(p.shape))
+    # oracle run: uncapped tree, per-body MAC, fp64 state
+    pos, vel = p.copy(), v.copy()
+    for _ in range(steps):
+        t = O.build_tree(pos, m, 0)
+        f = O.compute_forces(t, pos, m, compat_self_skip=False)
+        _, vel, pos = O.integrate(f, m, vel, pos)
+    d_ref = pos - p
+    assert np.abs(d_ref).max() < 1e-7                      # far below the fp32 spacing of coordinates ~0.1 (7e-9)...
+    out = {}
+    for prec in (G.Precision.MIXED, G.Precision.F32):
+        with engine(n, precision=prec) as e:
+            e.upload(p, v, m)
+            e.step(steps)
+            out[prec] = e.download()
+    d_mixed = out[G.Precision.MIXED][0] - p
+    r = np.linalg.norm(d_mixed - d_ref, axis=1) / np.linalg.norm(d_ref, axis=1)
+    assert np.median(r) < 1e-5 and np.quantile(r, 0.999) < 1e-3
+    dv = out[G.Precision.MIXED][1] - v
+    rv = np.linalg.norm(dv - (vel - v), axis=1) / np.linalg.norm(vel - v, axis=1)
+    assert np.median(rv) < 1e-5
+    # fp32 state: the same run cannot resolve these displacements
+    p32 = p.astype(np.float32).astype(np.float64)
+    d_f32 = out[G.Precision.F32][0] - p32
+    r32 = np.linalg.norm(d_f32 - d_ref, axis=1) / np.linalg.norm(d_ref, axis=1)
+    assert np.median(r32) > 0.1
+
+
+def test_mixed_let_forest_and_refusals():
+    n = 30000
+    m, p, v = IC.make("plummer", n, 6)
+    idx = np.arange(0, n, 53)
+    sub = np.zeros((len(idx), 2))
+    for k, i in enumerate(idx):
+        d = p - p[i]
+        r2 = (d ** 2).sum(1)
+        r2[i] = np.inf
+        sub[k] = (6.67e-11 * m[:, None] * d / (r2 ** 1.5)[:, None]).sum(0)
+    er = EmulatedRanks(m, p, v, 3, let_cap=8192, precision=G.Precision.MIXED, max_depth=21, reference_compat=False)
+    er.step(integrate=False)
+    a = er.gather(lambda e: e.accelerations())
+    er.step()                                              # integrates the fp64 state
+    pn = er.gather(lambda e: e.download()[0])
+    er.close()
+    with engine(n) as e:
+        e.upload(p, v, m)
+        e.compute_forces()
+        a1 = e.accelerations()
+        with pytest.raises(G.BhError) as ei:
+            e.step_local()
+        assert ei.value.code == -5
+        with pytest.raises(G.BhError):
+            e.device_sorted()
+    assert np.median(rel(a[idx], sub)) <= 1.2 * np.median(rel(a1[idx], sub)) + 1e-6
+    assert np.isfinite(pn).all() and not np.array_equal(pn, p)
