@@ -79,7 +79,7 @@ SIGNATURES = {
     "bh_let_configure": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int64]),
     "bh_let_bounds": (C.c_int, [_ctx]),
     "bh_let_pointers": (C.c_int, [_ctx, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
-                                  C.POINTER(C.c_int64)]),
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "bh_let_build": (C.c_int, [_ctx]),
     "bh_let_walk": (C.c_int, [_ctx]),
     "bh_let_forces": (C.c_int, [_ctx]),

@@ -303,12 +303,12 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted)
         const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0 || (3 * c->Dm + 2 > kWave);
         const int mode = c->let_mode ? 0 : c->walk_mode;
         // few bodies: several waves per 64-body group (bh_walk_fast.hip).  Measured best factor
-        // (scripts/split_sweep.py): 8 up to 32k bodies per launch, 4 up to 128k,
+        // (scripts/split_sweep.py): 8 up to 32k bodies per launch, 4 up to 192k,
         // one wave per group beyond.  BH_WALK_SPLIT overrides (1 = off).
         int split = (c->cfg.flags & BH_FLAG_WALK_NO_SPLIT) ? 1 : c->walk_split;
         if (split <= 0) {
             const int64_t groups = (hi - lo + kWave - 1) / kWave;
-            split = groups <= 512 ? 8 : groups <= 2048 ? 4 : 1;
+            split = groups <= 512 ? 8 : groups <= 3072 ? 4 : 1;
         }
         BH_HIP(c, launch_walk_fast(a, lds, stats, mode, c->walk_xcd, split, c->stream));
         if (walk_fast_split_effective(a, lds, mode, split)) per_partial = kWave;
@@ -902,7 +902,7 @@ int bh_let_configure(bh_ctx *c, int32_t rank, int32_t world, int64_t let_cap)
         A(&c->needmask, (size_t)c->quads_local);
         A(&c->let_tsum, (size_t)world * ntiles);
         A(&c->let_outidx, (size_t)world * c->quads_local);
-        A(&c->lbounds, 4); A(&c->all_bounds, 4 * (size_t)world);
+        A(&c->lbounds, 4 * kLetBoxes); A(&c->all_bounds, 4 * kLetBoxes * (size_t)world);
         A(&c->let_ctr, 1);
     }
     c->let_cap = let_cap;
@@ -922,23 +922,24 @@ int bh_let_bounds(bh_ctx *c)
     if (!c->uploaded) return fail(c, BH_ERR_STATE, "bh_let_bounds before bh_upload");
     BH_HIP(c, hipSetDevice(c->device));
     if (c->partial_count <= 0) {
-        const unsigned nbb = std::max(1u, std::min(1024u, blocks_for(c->n, kBlock)));
+        const unsigned nbb = kLetBoxes * kLetBoxParts;
         if (c->state64)
-            hipLaunchKernelGGL((bounds_partial<double2>), dim3(nbb), dim3(kBlock), 0, c->stream,
+            hipLaunchKernelGGL((let_slice_bounds_kernel<double2>), dim3(nbb), dim3(kBlock), 0, c->stream,
                                (const double2 *)c->pos, c->n, c->partial);
         else
-            hipLaunchKernelGGL((bounds_partial<float2>), dim3(nbb), dim3(kBlock), 0, c->stream,
+            hipLaunchKernelGGL((let_slice_bounds_kernel<float2>), dim3(nbb), dim3(kBlock), 0, c->stream,
                                (const float2 *)c->pos, c->n, c->partial);
         c->partial_count = (int)nbb;
     }
-    hipLaunchKernelGGL(let_local_bounds_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->partial, c->partial_count,
-                       c->lbounds);
+    hipLaunchKernelGGL(let_local_bounds_kernel, dim3(kLetBoxes), dim3(kWave), 0, c->stream, c->partial,
+                       c->partial_count, c->lbounds);
     c->partial_count = 0;
     BH_HIP(c, hipGetLastError());
     return BH_OK;
 }
 
-int bh_let_pointers(bh_ctx *c, void **lbounds, void **all_bounds, void **send, void **recv, int64_t *block_bytes)
+int bh_let_pointers(bh_ctx *c, void **lbounds, void **all_bounds, void **send, void **recv, int64_t *block_bytes,
+                    int32_t *boxes_per_rank)
 {
     if (!c || !c->let_mode) return fail(c, BH_ERR_STATE, "bh_let_pointers: call bh_let_configure first");
     if (lbounds) *lbounds = c->lbounds;
@@ -946,6 +947,7 @@ int bh_let_pointers(bh_ctx *c, void **lbounds, void **all_bounds, void **send, v
     if (send) *send = c->let_send;
     if (recv) *recv = c->qf + c->quads_local;
     if (block_bytes) *block_bytes = c->let_cap * (int64_t)sizeof(QuadF);
+    if (boxes_per_rank) *boxes_per_rank = kLetBoxes;
     return BH_OK;
 }
 
@@ -955,7 +957,8 @@ int bh_let_build(bh_ctx *c)
     if (!c->uploaded) return fail(c, BH_ERR_STATE, "bh_let_build before bh_upload");
     BH_HIP(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    hipLaunchKernelGGL(let_box_kernel, dim3(1), dim3(64), 0, st, c->all_bounds, c->world, c->box, c->ctr, c->let_ctr);
+    hipLaunchKernelGGL(let_box_kernel, dim3(1), dim3(64), 0, st, c->all_bounds, c->world * kLetBoxes, c->box, c->ctr,
+                       c->let_ctr);
     int rc = enqueue_build(c);
     if (rc) return rc;
     const int64_t nq = c->quads_local;

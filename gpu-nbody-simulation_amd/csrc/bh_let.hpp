@@ -1,14 +1,17 @@
 // bh_let.hpp -- locally-essential-tree (LET) extraction for the distributed step.
 // The reference is single-GPU; this is new design.
 //
-// Each rank owns a set of bodies (initially a contiguous chunk of the Hilbert order, so a compact
-// region) and builds its LOCAL tree with the usual pipeline, but under the GLOBAL root box, so its
-// cells are cells of the global grid.  The force on a body is the sum of its walks over the W local
-// trees (a forest); per-body MAC as everywhere else.  For the remote trees a rank does not need
-// whole trees, only the part its bodies can open:
+// Each rank owns a set of bodies -- a contiguous range of the Hilbert order of the initial positions
+// (distributed.partition_hilbert), so its 64-body wave groups are the groups a single GPU would form
+// -- and builds its LOCAL tree with the usual pipeline, but under the GLOBAL root box, so its cells
+// are cells of the global grid.  The force on a body is the sum of its walks over the W local trees
+// (a forest); per-body MAC as everywhere else.  For the remote trees a rank does not need whole
+// trees, only the part its bodies can open.  A rank describes where its bodies are by kLetBoxes
+// bounding boxes (of consecutive slices of its bodies: a Hilbert range is a compact but not a
+// rectangular region, one box would overlap the neighbours'); then
 //
 //   a node of rank r's tree can be opened by SOME body of peer q only if
-//        dist^2(node COM, bounding box of q's bodies) <= (size/theta)^2 = thr
+//        dist^2(node COM, some box of q) <= (size/theta)^2 = thr
 //   (every body of q is at least that far away; a body opens a node iff d^2 <= thr).
 //
 // That test is local to the node, so marking is one pass over the quads with no traversal:
@@ -31,6 +34,8 @@
 namespace bh {
 
 constexpr int kMaxWorld = 64;
+constexpr int kLetBoxes = 8;       // bounding boxes per rank
+constexpr int kLetBoxParts = 16;   // first step: partial blocks per box
 
 struct LetCounters {
     uint32_t count[kMaxWorld];   // quads packed for each peer
@@ -38,14 +43,14 @@ struct LetCounters {
     uint32_t pad[3];
 };
 
-// all_bounds: world x {xmin, xmax, ymin, ymax} raw (unpadded) bounds of every rank's bodies.
-// One thread: global box with the reference's padding (project.cu:553-570).
-__global__ void let_box_kernel(const double *__restrict__ all_bounds, int world, double *__restrict__ box,
+// all_bounds: (world * kLetBoxes) x {xmin, xmax, ymin, ymax} raw (unpadded) bounds of slices of every
+// rank's bodies.  One thread: global box with the reference's padding (project.cu:553-570).
+__global__ void let_box_kernel(const double *__restrict__ all_bounds, int nboxes, double *__restrict__ box,
                                TreeCounters *ctr, LetCounters *lc)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
-    for (int r = 0; r < world; ++r) {
+    for (int r = 0; r < nboxes; ++r) {
         const double a = all_bounds[4 * r], b = all_bounds[4 * r + 1], c = all_bounds[4 * r + 2], d = all_bounds[4 * r + 3];
         xlo = (a < xlo) ? a : xlo;  xhi = (xhi < b) ? b : xhi;
         ylo = (c < ylo) ? c : ylo;  yhi = (yhi < d) ? d : yhi;
@@ -61,16 +66,21 @@ __global__ void let_box_kernel(const double *__restrict__ all_bounds, int world,
     lc->overflow = 0;
 }
 
-// raw min/max of the local bodies (no padding) from the per-workgroup partials
-__global__ __launch_bounds__(kBlock) void let_local_bounds_kernel(const double *__restrict__ partial, int nb,
-                                                                   double *__restrict__ lbounds)
+// First step (no partials from a walk yet): min/max of kLetBoxes * kLetBoxParts CONTIGUOUS slices of
+// the bodies in caller order (distributed.partition_hilbert hands them over in Hilbert order, so a
+// slice is a compact region; any order is correct).
+template <typename Real2>
+__global__ __launch_bounds__(kBlock) void let_slice_bounds_kernel(const Real2 *__restrict__ pos, int64_t n,
+                                                                   double *__restrict__ partial)
 {
     __shared__ double sm[4][kWavesPerBlock];
+    const int64_t nb = gridDim.x;
+    const int64_t lo = n * blockIdx.x / nb, hi = n * (blockIdx.x + 1) / nb;
     double xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
-    for (int i = threadIdx.x; i < nb; i += kBlock) {
-        const double a = partial[4 * i], b = partial[4 * i + 1], c = partial[4 * i + 2], d = partial[4 * i + 3];
-        xlo = (a < xlo) ? a : xlo;  xhi = (xhi < b) ? b : xhi;
-        ylo = (c < ylo) ? c : ylo;  yhi = (yhi < d) ? d : yhi;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+        const double x = (double)pos[i].x, y = (double)pos[i].y;
+        xlo = (x < xlo) ? x : xlo;  xhi = (xhi < x) ? x : xhi;
+        ylo = (y < ylo) ? y : ylo;  yhi = (yhi < y) ? y : yhi;
     }
     xlo = wave_min(xlo); xhi = wave_max(xhi); ylo = wave_min(ylo); yhi = wave_max(yhi);
     if (lane_id() == 0) { sm[0][wave_id()] = xlo; sm[1][wave_id()] = xhi; sm[2][wave_id()] = ylo; sm[3][wave_id()] = yhi; }
@@ -80,7 +90,29 @@ __global__ __launch_bounds__(kBlock) void let_local_bounds_kernel(const double *
             xlo = (sm[0][w] < xlo) ? sm[0][w] : xlo;  xhi = (xhi < sm[1][w]) ? sm[1][w] : xhi;
             ylo = (sm[2][w] < ylo) ? sm[2][w] : ylo;  yhi = (yhi < sm[3][w]) ? sm[3][w] : yhi;
         }
-        lbounds[0] = xlo; lbounds[1] = xhi; lbounds[2] = ylo; lbounds[3] = yhi;
+        double *o = partial + 4 * (size_t)blockIdx.x;
+        o[0] = xlo; o[1] = xhi; o[2] = ylo; o[3] = yhi;
+    }
+}
+
+// kLetBoxes boxes of this rank: box k = min/max over the k-th run of consecutive partials (partials
+// come from the walk's epilogue -- one per group of sorted bodies, so a run is a stretch of the Hilbert
+// order -- or from let_slice_bounds_kernel).  One wave per box.
+__global__ __launch_bounds__(kWave) void let_local_bounds_kernel(const double *__restrict__ partial, int nb,
+                                                                  double *__restrict__ lbounds)
+{
+    const int k = blockIdx.x;
+    const int lo = (int)((int64_t)nb * k / kLetBoxes), hi = (int)((int64_t)nb * (k + 1) / kLetBoxes);
+    double xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
+    for (int i = lo + threadIdx.x; i < hi; i += kWave) {
+        const double a = partial[4 * i], b = partial[4 * i + 1], c = partial[4 * i + 2], d = partial[4 * i + 3];
+        xlo = (a < xlo) ? a : xlo;  xhi = (xhi < b) ? b : xhi;
+        ylo = (c < ylo) ? c : ylo;  yhi = (yhi < d) ? d : yhi;
+    }
+    xlo = wave_min(xlo); xhi = wave_max(xhi); ylo = wave_min(ylo); yhi = wave_max(yhi);
+    if (threadIdx.x == 0) {
+        double *o = lbounds + 4 * k;                       // an empty run stays (+inf, -inf): matches nothing
+        o[0] = xlo; o[1] = xhi; o[2] = ylo; o[3] = yhi;
     }
 }
 
@@ -90,12 +122,12 @@ __global__ __launch_bounds__(kBlock) void let_mark_kernel(const QuadF *__restric
                                                            int rank, const TreeCounters *__restrict__ ctr,
                                                            int64_t internal_cap, uint64_t *__restrict__ needmask)
 {
-    __shared__ float sbox[kMaxWorld][4];
-    if (threadIdx.x < world) {
+    __shared__ float sbox[kMaxWorld * kLetBoxes][4];
+    for (int i = threadIdx.x; i < world * kLetBoxes; i += kBlock) {
         // outward-rounded float copies of the peers' boxes (the test must stay conservative)
-        const double *b = all_bounds + 4 * threadIdx.x;
-        sbox[threadIdx.x][0] = __double2float_rd(b[0]); sbox[threadIdx.x][1] = __double2float_ru(b[1]);
-        sbox[threadIdx.x][2] = __double2float_rd(b[2]); sbox[threadIdx.x][3] = __double2float_ru(b[3]);
+        const double *b = all_bounds + 4 * i;
+        sbox[i][0] = __double2float_rd(b[0]); sbox[i][1] = __double2float_ru(b[1]);
+        sbox[i][2] = __double2float_rd(b[2]); sbox[i][3] = __double2float_ru(b[3]);
     }
     __syncthreads();
     const uint32_t total = ctr->n_internal;
@@ -114,9 +146,15 @@ __global__ __launch_bounds__(kBlock) void let_mark_kernel(const QuadF *__restric
         uint64_t mask = 0;
         for (int p = 0; p < world; ++p) {
             if (p == rank) continue;
-            const float dx = fmaxf(fmaxf(sbox[p][0] - cx, cx - sbox[p][1]), 0.f);
-            const float dy = fmaxf(fmaxf(sbox[p][2] - cy, cy - sbox[p][3]), 0.f);
-            if (dx * dx + dy * dy <= thr) mask |= 1ull << p;   // an empty peer box (inf) gives inf: no
+            bool near = false;
+#pragma unroll
+            for (int b = 0; b < kLetBoxes; ++b) {
+                const float *bx = sbox[p * kLetBoxes + b];
+                const float dx = fmaxf(fmaxf(bx[0] - cx, cx - bx[1]), 0.f);
+                const float dy = fmaxf(fmaxf(bx[2] - cy, cy - bx[3]), 0.f);
+                near = near || (dx * dx + dy * dy <= thr);     // an empty box (inf) gives inf: no
+            }
+            if (near) mask |= 1ull << p;
         }
         needmask[child] = mask;
     }

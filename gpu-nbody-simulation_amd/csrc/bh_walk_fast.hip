@@ -24,7 +24,7 @@
 //     perm), or into the sorted arrays for the multi-GPU exchange; plus the per-workgroup min/max of
 //     the new positions for the next step's root box.
 //   * BH_WALK_PIPE / BH_WALK_XCD select measured-and-rejected loop variants.
-//   * SPLIT > 1 (few bodies: N <= 128k on one GPU, or one rank's share of a multi-GPU run).  The
+//   * SPLIT > 1 (few bodies: N <= 192k on one GPU, or one rank's share of a multi-GPU run).  The
 //     walk of a 64-body group is a dependent chain of ~200 quad visits; a lone wave spends ~370
 //     cycles waiting for each quad and ~1000 issuing its evaluation (measured with s_memtime),
 //     ~0.1 ms in all however empty the GPU is, while a SIMD with 16 resident waves retires a quad

@@ -220,11 +220,13 @@ class BarnesHutEngine:
         self._check(self._lib.bh_let_bounds(self._h))
 
     def let_pointers(self):
-        """(lbounds, all_bounds, send, recv, block_bytes) device pointers for the two collectives."""
+        """(lbounds, all_bounds, send, recv, block_bytes, boxes_per_rank): device pointers for the two
+        collectives; lbounds holds boxes_per_rank x 4 doubles, all_bounds world times that."""
         a, b, s, r = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-        nb = C.c_int64()
-        self._check(self._lib.bh_let_pointers(self._h, C.byref(a), C.byref(b), C.byref(s), C.byref(r), C.byref(nb)))
-        return a.value, b.value, s.value, r.value, nb.value
+        nb, k = C.c_int64(), C.c_int32()
+        self._check(self._lib.bh_let_pointers(self._h, C.byref(a), C.byref(b), C.byref(s), C.byref(r), C.byref(nb),
+                                              C.byref(k)))
+        return a.value, b.value, s.value, r.value, nb.value, k.value
 
     def let_build(self) -> None:
         self._check(self._lib.bh_let_build(self._h))

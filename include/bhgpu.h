@@ -58,7 +58,7 @@ typedef enum bh_precision {
 #define BH_FLAG_LDS_STACK    (1u << 1)  /* fp32 walk: LDS traversal stack instead of the
                                            register-lane stack (A/B switch)  */
 #define BH_FLAG_WALK_NO_SPLIT (1u << 2) /* fp32 walk: always one wavefront per 64 bodies.  By
-                                           default a launch of few bodies (<= 128k: small N, or
+                                           default a launch of few bodies (<= 192k: small N, or
                                            one rank's share) lets 4 or 8 wavefronts share each
                                            64-body group, level by level; same nodes, same
                                            per-body criterion, but another order of the fp32
@@ -196,11 +196,13 @@ int bh_step_local(bh_ctx *ctx);
 int bh_device_sorted(bh_ctx *ctx, void **sorted_pos, void **sorted_vel);
 int bh_scatter_sorted(bh_ctx *ctx);
 /* Distributed step with locally-essential trees (LET).  Unlike the replicated scheme above, a
- * context in LET mode holds ONLY ITS OWN bodies (bh_upload its subset).  Per step:
- *   bh_let_bounds   -> raw min/max of the local bodies in a device buffer (4 doubles)
- *   [host: all_gather the W x 4 doubles into the all_bounds buffer]
+ * context in LET mode holds ONLY ITS OWN bodies (bh_upload its subset; a contiguous range of a
+ * space-filling-curve order of the bodies keeps the exchanged trees small).  Per step:
+ *   bh_let_bounds   -> B = boxes_per_rank bounding boxes of consecutive slices of the local bodies
+ *                      in a device buffer (B x 4 doubles: xmin, xmax, ymin, ymax; unpadded)
+ *   [host: all_gather the W x B x 4 doubles into the all_bounds buffer]
  *   bh_let_build    -> global root box, local tree under it, and for every peer a compact LET
- *                      (the quads that some body inside the peer's bounding box can open) packed
+ *                      (the quads that some body inside one of the peer's boxes can open) packed
  *                      in the send buffer, W fixed-size blocks of let_cap quads, child links
  *                      already expressed in the receiver's index space
  *   [host: all_to_all of the blocks, send buffer -> recv buffer]
@@ -212,11 +214,11 @@ int bh_scatter_sorted(bh_ctx *ctx);
  * truncated safely (links past the block are cut), so the step completes but its forces are wrong:
  * check the counts before trusting a run.  bh_let_configure may be called again with the same
  * rank/world and a new let_cap (size the blocks from measured counts).  bh_let_forces =
- * bh_let_walk without the integration.  fp32 mode only. */
+ * bh_let_walk without the integration.  fp32 and mixed precision. */
 int bh_let_configure(bh_ctx *ctx, int32_t rank, int32_t world, int64_t let_cap);
 int bh_let_bounds(bh_ctx *ctx);
 int bh_let_pointers(bh_ctx *ctx, void **lbounds, void **all_bounds, void **send, void **recv,
-                    int64_t *block_bytes);
+                    int64_t *block_bytes, int32_t *boxes_per_rank);
 int bh_let_build(bh_ctx *ctx);
 int bh_let_walk(bh_ctx *ctx);
 int bh_let_forces(bh_ctx *ctx);

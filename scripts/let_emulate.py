@@ -22,7 +22,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gpu_nbody_simulation_amd as G  # noqa: E402
 from gpu_nbody_simulation_amd import initial_conditions as IC  # noqa: E402
-from gpu_nbody_simulation_amd.distributed import partition_orb, wrap_device  # noqa: E402
+from gpu_nbody_simulation_amd.distributed import partition_hilbert, partition_orb, wrap_device  # noqa: E402
 
 
 def main():
@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--worlds", default="2,4,8")
     ap.add_argument("--init", default="plummer")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--partition", choices=["hilbert", "orb", "orb-nosnap"], default="orb")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     n = a.n
@@ -62,13 +63,14 @@ def main():
                     e._check(e._lib.bh_compute_forces(e._h))
                 rep.append((time.perf_counter() - t0) / a.reps * 1e3)
         # ---- LET
-        parts = partition_orb(p, world)
+        parts = (partition_hilbert(p, world) if a.partition == "hilbert"
+                 else partition_orb(p, world, snap=a.partition == "orb"))
         cap_bodies = max(len(ix) for ix in parts)
         engs, bufs = [], []
 
         def wire(e):
-            lb, ab, sd, rv, nb = e.let_pointers()
-            return (wrap_device(lb, 4, "<f8", dev), wrap_device(ab, 4 * world, "<f8", dev),
+            lb, ab, sd, rv, nb, k = e.let_pointers()
+            return (wrap_device(lb, 4 * k, "<f8", dev), wrap_device(ab, 4 * k * world, "<f8", dev),
                     wrap_device(sd, world * nb, "|u1", dev), wrap_device(rv, world * nb, "|u1", dev), nb)
 
         for r, ix in enumerate(parts):
@@ -123,7 +125,8 @@ def main():
         res["rows"].append(row)
         print(json.dumps(row), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/let_emulate_{a.init}_{n}.json", "w") as fh:
+    res["partition"] = a.partition
+    with open(f"gpurun_out/let_emulate_{a.init}_{n}_{a.partition}.json", "w") as fh:
         json.dump(res, fh, indent=1)
 
 

@@ -92,6 +92,7 @@ class LetStandInEngine:
     orchestration: the all_gather of bounds, the block routing of the all_to_all, autotune and the
     overflow check.  The device-side LET logic is covered by tests/test_gpu_let.py."""
     QUAD_BYTES = 80
+    BOXES = 8
 
     def __init__(self, G=6.67e-11, dt=1.0):
         self.G, self.dt = G, dt
@@ -108,25 +109,26 @@ class LetStandInEngine:
     def let_configure(self, rank, world, let_cap):
         self.rank, self.world, self.let_cap = rank, world, let_cap
         nb = let_cap * self.QUAD_BYTES
-        self.lbounds = torch.zeros(4, dtype=torch.float64)
-        self.all_bounds = torch.zeros(4 * world, dtype=torch.float64)
+        self.lbounds = torch.zeros(4 * self.BOXES, dtype=torch.float64)
+        self.all_bounds = torch.zeros(4 * self.BOXES * world, dtype=torch.float64)
         self.send = torch.zeros(world * nb, dtype=torch.uint8)
         self.recv = torch.zeros(world * nb, dtype=torch.uint8)
         self.counts, self.overflow = [0] * world, False
 
     def let_pointers(self):
-        return self.lbounds, self.all_bounds, self.send, self.recv, self.let_cap * self.QUAD_BYTES
+        return self.lbounds, self.all_bounds, self.send, self.recv, self.let_cap * self.QUAD_BYTES, self.BOXES
 
     def let_bounds(self):
-        if self.n:
-            b = [self.pos[:, 0].min(), self.pos[:, 0].max(), self.pos[:, 1].min(), self.pos[:, 1].max()]
-        else:
-            b = [np.inf, -np.inf, np.inf, -np.inf]
-        self.lbounds[:] = torch.tensor(b, dtype=torch.float64)
+        b = np.tile(np.array([np.inf, -np.inf, np.inf, -np.inf]), (self.BOXES, 1))
+        for k in range(self.BOXES):
+            sl = self.pos[self.n * k // self.BOXES: self.n * (k + 1) // self.BOXES]
+            if len(sl):
+                b[k] = [sl[:, 0].min(), sl[:, 0].max(), sl[:, 1].min(), sl[:, 1].max()]
+        self.lbounds[:] = torch.from_numpy(b.reshape(-1))
 
     def let_build(self):
         nb = self.let_cap * self.QUAD_BYTES
-        self.seen_bounds = self.all_bounds.numpy().reshape(self.world, 4).copy()
+        self.seen_bounds = self.all_bounds.numpy().reshape(self.world, self.BOXES, 4).copy()
         rec = np.concatenate([self.pos, self.mass[:, None]], axis=1).astype(np.float32).reshape(-1)
         need = 12 + rec.nbytes
         quads = (need + self.QUAD_BYTES - 1) // self.QUAD_BYTES

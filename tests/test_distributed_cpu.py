@@ -92,12 +92,12 @@ def _let_worker(rank, world, port, n, steps, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from dist_standin import LetStandInEngine
-    from gpu_nbody_simulation_amd.distributed import LetStepper, partition_orb
+    from gpu_nbody_simulation_amd.distributed import LetStepper, partition_hilbert
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     m, p, v = _inputs(n)
-    mine = partition_orb(p, world)[rank]
+    mine = partition_hilbert(p, world, align=16)[rank]
     eng = LetStandInEngine()
     eng.upload(p[mine], v[mine], m[mine])
     st = LetStepper(eng, rank, world, let_cap=2, device=torch.device("cpu"))   # far too small on purpose
@@ -143,7 +143,7 @@ def test_let_stepper_ranks_reproduce_the_direct_sum(tmp_path, world, n):
         assert int(d["largest"]) <= int(d["cap"])          # ... and autotune fixed it
         # every rank saw every rank's bounds, in rank order
         b = d["bounds"]
-        assert b.shape == (world, 4) and np.isfinite(b).all() and (b[:, 0] <= b[:, 1]).all()
+        assert b.shape == (world, 8, 4) and np.isfinite(b).all() and (b[..., 0] <= b[..., 1]).all()
         if r:
             assert np.array_equal(b, first_bounds)
         first_bounds = b
@@ -163,10 +163,47 @@ def test_partition_orb_is_a_balanced_partition_into_disjoint_boxes():
         allidx = np.sort(np.concatenate(parts))
         assert np.array_equal(allidx, np.arange(1000))
         sizes = [len(x) for x in parts]
-        assert max(sizes) - min(sizes) <= world
+        assert max(sizes) - min(sizes) <= 0.05 * 1000 / world + world   # a snapped cut moves <= 1 % of a piece's bodies
+        exact = [len(x) for x in partition_orb(p, world, snap=False)]
+        assert max(exact) - min(exact) <= world
         boxes = [(p[ix].min(0), p[ix].max(0)) for ix in parts]
         for i in range(world):
             for j in range(i + 1, world):
                 (alo, ahi), (blo, bhi) = boxes[i], boxes[j]
                 overlap = np.all(np.minimum(ahi, bhi) - np.maximum(alo, blo) > 0)
                 assert not overlap
+
+
+def test_partition_hilbert_is_a_partition_into_compact_curve_ranges():
+    from gpu_nbody_simulation_amd.distributed import hilbert_index, partition_hilbert
+    # the index is a bijection of the grid and consecutive cells are neighbours
+    g = np.stack(np.meshgrid(np.arange(16), np.arange(16), indexing="ij"), -1).reshape(-1, 2).astype(float)
+    d = hilbert_index(g, bits=4)
+    assert sorted(d.tolist()) == list(range(256))
+    walk = g[np.argsort(d)]
+    assert (np.abs(np.diff(walk, axis=0)).sum(1) == 1).all()
+    rng = np.random.default_rng(0)
+    p = rng.normal(size=(10000, 2))
+    for world in (1, 2, 3, 8):
+        parts = partition_hilbert(p, world)
+        assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(10000))
+        for ix in parts[:-1]:
+            assert len(ix) % 256 == 0                       # wave groups never straddle two ranks
+        sizes = [len(x) for x in parts]
+        assert max(sizes) - min(sizes) <= 512
+        # compact: a rank's bounding box area is far below the whole (8 ranks)
+        if world == 8:
+            area = [np.prod(np.ptp(p[ix], axis=0)) for ix in parts]
+            assert np.median(area) < 0.25 * np.prod(np.ptp(p, axis=0))
+
+
+def test_partition_orb_snaps_the_cut_of_a_symmetric_input_to_the_grid_line():
+    from gpu_nbody_simulation_amd.distributed import partition_orb
+    rng = np.random.default_rng(3)
+    p = rng.uniform(-0.1, 0.1, (20000, 2))
+    p[0], p[1] = (-0.1, -0.1), (0.1, 0.1)                    # the box is exactly symmetric: midline at 0
+    lo, hi = partition_orb(p, 2)
+    ax = 0 if p[lo][:, 0].max() <= 0 or p[hi][:, 0].min() >= 0 else 1
+    assert p[lo][:, ax].max() < 0 <= p[hi][:, ax].min()      # no body on the wrong side of the midline
+    lo2, hi2 = partition_orb(p, 2, snap=False)
+    assert abs(len(lo2) - len(hi2)) <= 1

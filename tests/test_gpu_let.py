@@ -18,13 +18,13 @@ pytestmark = pytest.mark.gpu
 from oracle import bh_oracle as O  # noqa: E402
 import gpu_nbody_simulation_amd as G  # noqa: E402
 from gpu_nbody_simulation_amd import initial_conditions as IC  # noqa: E402
-from gpu_nbody_simulation_amd.distributed import partition_orb, wrap_device  # noqa: E402
+from gpu_nbody_simulation_amd.distributed import partition_hilbert, partition_orb, wrap_device  # noqa: E402
 
 
 class EmulatedRanks:
-    def __init__(self, mass, pos, vel, world, let_cap, **cfg):
+    def __init__(self, mass, pos, vel, world, let_cap, partition=partition_orb, **cfg):
         self.world = world
-        self.parts = partition_orb(pos, world)
+        self.parts = partition(pos, world)
         dev = torch.device("cuda", 0)
         self.engs, self.bufs = [], []
         cap = max(len(ix) for ix in self.parts)
@@ -33,8 +33,8 @@ class EmulatedRanks:
             e = G.BarnesHutEngine(G.BhConfig(capacity=cap, **cfg))
             e.upload(pos[ix], vel[ix], mass[ix])
             e.let_configure(r, world, let_cap)
-            lb, ab, sd, rv, nb = e.let_pointers()
-            self.bufs.append((wrap_device(lb, 4, "<f8", dev), wrap_device(ab, 4 * world, "<f8", dev),
+            lb, ab, sd, rv, nb, k = e.let_pointers()
+            self.bufs.append((wrap_device(lb, 4 * k, "<f8", dev), wrap_device(ab, 4 * k * world, "<f8", dev),
                               wrap_device(sd, world * nb, "|u1", dev), wrap_device(rv, world * nb, "|u1", dev), nb))
             self.engs.append(e)
 
