@@ -206,8 +206,11 @@ class LetStepper:
     sizes them once from measured LET sizes, and check() (call it outside timed regions, every so
     often) raises if a LET has outgrown its block since."""
 
-    def __init__(self, engine, rank: int, world: int, let_cap: int, device: torch.device | None = None):
+    def __init__(self, engine, rank: int, world: int, let_cap: int, device: torch.device | None = None,
+                 ids=None):
+        """ids: global identifiers of this rank's bodies in upload order (kept through repartition())."""
         self.eng, self.rank, self.world, self.device = engine, rank, world, device
+        self.ids = ids
         self._configure(let_cap)
 
     def _configure(self, let_cap: int) -> None:
@@ -265,3 +268,31 @@ class LetStepper:
             raise RuntimeError(f"a locally-essential tree outgrew let_cap={self.let_cap} (largest {mx}); "
                                "results since the last check are invalid -- autotune() again")
         return mx
+
+    def repartition(self, partition=partition_orb) -> int:
+        """Re-deal the bodies to the ranks (bodies drift; a rank's bodies spread, its boxes overlap its
+        neighbours' and the LETs grow).  Set-up-grade: the state goes through the host and the object
+        collectives; call it every few hundred steps, not every step.  Needs `ids`; returns the number
+        of bodies this rank holds afterwards (the engine's capacity must allow it)."""
+        import numpy as np
+        if self.ids is None:
+            raise ValueError("LetStepper.repartition needs the bodies' global ids (ids=...)")
+        pos, vel = self.eng.download()
+        mine = (np.asarray(self.ids), pos, vel, self.eng.masses())
+        if dist.is_initialized() and self.world > 1:
+            pieces = [None] * self.world
+            dist.all_gather_object(pieces, mine)
+        else:
+            pieces = [mine]
+        ids = np.concatenate([x[0] for x in pieces])
+        order = np.argsort(ids, kind="stable")             # every rank sees the same global arrays
+        ids = ids[order]
+        pos = np.concatenate([x[1] for x in pieces])[order]
+        vel = np.concatenate([x[2] for x in pieces])[order]
+        mass = np.concatenate([x[3] for x in pieces])[order]
+        sel = partition(pos, self.world)[self.rank]
+        self.eng.upload(pos[sel], vel[sel], mass[sel])
+        self.ids = ids[sel]
+        self.autotune()
+        return len(sel)
+

@@ -106,6 +106,9 @@ class LetStandInEngine:
     def download(self):
         return self.pos.astype(np.float64), self.vel.astype(np.float64)
 
+    def masses(self):
+        return self.mass.astype(np.float64)
+
     def let_configure(self, rank, world, let_cap):
         self.rank, self.world, self.let_cap = rank, world, let_cap
         nb = let_cap * self.QUAD_BYTES
