@@ -46,6 +46,7 @@ struct bh_ctx {
     int sort_passes = 0;
     bool state64 = false;          // fp64 state arrays: exact and mixed precision
     int walk_mode = 0; bool walk_xcd = false; int walk_split = 0;   // 0 = automatic
+    int build_items = 0;           // 0 = automatic, else keys per thread in the sort / scan kernels (2, 4, 8)
     bool hilbert = false;                // fp32 mode: Hilbert-ordered keys (BH_HILBERT=0 disables, A/B)  // BH_WALK_PIPE / BH_WALK_XCD override (A/B)
     int partial_count = 0;         // > 0: partial[] holds per-workgroup min/max of the current positions
 
@@ -151,9 +152,14 @@ void owned_range(const bh_ctx *c, int64_t *lo, int64_t *hi)
     *hi = std::min<int64_t>(c->n, chunk * (c->rank + 1));
 }
 
-template <bool EXACT, bool STATE64 = EXACT>
+constexpr int64_t kSmallBuildBodies = 327680;    // up to here: tiles of 512 instead of 2,048 (measured)
+constexpr int64_t kMediumBuildBodies = 786432;   // up to here: tiles of 1,024
+constexpr int kSmallItems = 2;
+
+template <bool EXACT, bool STATE64 = EXACT, int ITEMS = kItems>
 int enqueue_build_t(bh_ctx *c)
 {
+    constexpr int TILE = kBlock * ITEMS;
     static_assert(!EXACT || STATE64, "exact mode keeps its state in fp64");
     using Real2 = typename std::conditional<STATE64, double2, float2>::type;   // the state
     using Real = typename std::conditional<STATE64, double, float>::type;
@@ -183,7 +189,7 @@ int enqueue_build_t(bh_ctx *c)
         else
             hipLaunchKernelGGL((keys_kernel<Real2, false>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
                                c->box, c->keys[0], c->vals[0], n, Dm);
-        const unsigned nbl = blocks_for(n, kSortTile);
+        const unsigned nbl = blocks_for(n, ITEMS == kItems ? kSortTile : TILE);
         int cur = 0;
         if (c->sort_onesweep && c->sort_passes > 0) {
             const int P = c->sort_passes;
@@ -202,13 +208,13 @@ int enqueue_build_t(bh_ctx *c)
         } else
         for (int p = 0; p < c->sort_passes; ++p) {
             const int shift = p * kRadixBits;
-            hipLaunchKernelGGL(radix_hist, dim3(nbl), dim3(kBlock), 0, st, c->keys[cur], c->radix_counts, n, shift,
-                               (int)nbl);
+            hipLaunchKernelGGL((radix_hist<ITEMS == kItems ? kSortItems : ITEMS>), dim3(nbl), dim3(kBlock), 0, st,
+                               c->keys[cur], c->radix_counts, n, shift, (int)nbl);
             hipLaunchKernelGGL(radix_rowscan, dim3(kRadix), dim3(kBlock), 0, st, c->radix_counts, c->bsum_sort,
                                (int)nbl);
-            hipLaunchKernelGGL(radix_scatter, dim3(nbl), dim3(kBlock), 0, st, c->keys[cur], c->vals[cur],
-                               c->keys[cur ^ 1], c->vals[cur ^ 1], c->radix_counts, c->bsum_sort, n, shift,
-                               (int)nbl);
+            hipLaunchKernelGGL((radix_scatter<ITEMS == kItems ? kSortItems : ITEMS>), dim3(nbl), dim3(kBlock), 0, st,
+                               c->keys[cur], c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1], c->radix_counts,
+                               c->bsum_sort, n, shift, (int)nbl);
             cur ^= 1;
         }
         c->keys_sorted = c->keys[cur];
@@ -216,16 +222,22 @@ int enqueue_build_t(bh_ctx *c)
 
         // 4. cells owned by each sorted neighbour pair (+ fp32: sorted copies and prefix-sum terms),
         // 5. their ranks / the prefix sums
-        const unsigned nbs = blocks_for(n + 1, kTile);
+        const unsigned nbs = blocks_for(n + 1, TILE);
         using SReal2 = typename std::conditional<EXACT, double2, float2>::type;    // what the walk reads
         using SReal = typename std::conditional<EXACT, double, float>::type;
-        hipLaunchKernelGGL((prep_kernel<EXACT, Real2, Real, SReal2, SReal>), dim3(nbs), dim3(kBlock), 0, st,
+        hipLaunchKernelGGL((prep_kernel<EXACT, ITEMS, Real2, Real, SReal2, SReal>), dim3(nbs), dim3(kBlock), 0, st,
                            c->keys_sorted, c->perm, pos, mass, c->cnt, c->bsum_u32, (SReal2 *)c->spos,
                            (SReal *)c->smass, c->terms, c->bsum_d3, c->coarse, n, Dm);
-        hipLaunchKernelGGL(scan_top2, dim3(EXACT ? 1 : 2), dim3(kBlock), 0, st, c->bsum_u32, c->bsum_d3, (int)nbs,
-                           c->ctr);
-        hipLaunchKernelGGL((scan_apply2<EXACT>), dim3(nbs), dim3(kBlock), 0, st, c->cnt, c->bsum_u32, c->terms,
-                           c->bsum_d3, n, c->cell_first, c->internal_cap);
+        if (nbs <= (unsigned)kBlock) {
+            // few tiles: every workgroup sums the tile totals before it itself (no scan_top2 launch)
+            hipLaunchKernelGGL((scan_apply2<EXACT, ITEMS, true>), dim3(nbs), dim3(kBlock), 0, st, c->cnt, c->bsum_u32,
+                               c->terms, c->bsum_d3, (int)nbs, n, c->cell_first, c->internal_cap, c->ctr);
+        } else {
+            hipLaunchKernelGGL(scan_top2, dim3(EXACT ? 1 : 2), dim3(kBlock), 0, st, c->bsum_u32, c->bsum_d3, (int)nbs,
+                               c->ctr);
+            hipLaunchKernelGGL((scan_apply2<EXACT, ITEMS, false>), dim3(nbs), dim3(kBlock), 0, st, c->cnt, c->bsum_u32,
+                               c->terms, c->bsum_d3, (int)nbs, n, c->cell_first, c->internal_cap, c->ctr);
+        }
     } else {
         c->keys_sorted = c->keys[0];
         c->perm = c->vals[0];
@@ -261,10 +273,25 @@ int enqueue_build_t(bh_ctx *c)
     return BH_OK;
 }
 
+template <int ITEMS>
+static int enqueue_build_items(bh_ctx *c)
+{
+    if (c->exact) return enqueue_build_t<true, true, ITEMS>(c);
+    return c->state64 ? enqueue_build_t<false, true, ITEMS>(c) : enqueue_build_t<false, false, ITEMS>(c);
+}
+
 int enqueue_build(bh_ctx *c)
 {
-    if (c->exact) return enqueue_build_t<true>(c);
-    return c->state64 ? enqueue_build_t<false, true>(c) : enqueue_build_t<false, false>(c);
+    // keys per thread in the sort / scan kernels: launches of few bodies take smaller tiles (more
+    // workgroups, fewer sequential rounds in each); BH_BUILD_ITEMS = 2, 4 or 8 overrides
+    int items = c->build_items;
+    if (items == 0) items = c->n <= kSmallBuildBodies ? 2 : c->n <= kMediumBuildBodies ? 4 : 8;
+    if (c->sort_onesweep || c->n > (1 << 22)) items = 8;         // (scratch for small tiles is sized for 4M bodies)
+    switch (items) {
+    case 2: return enqueue_build_items<2>(c);
+    case 4: return enqueue_build_items<4>(c);
+    default: return enqueue_build_items<kItems>(c);
+    }
 }
 
 int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted)
@@ -371,6 +398,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     if (const char *e = std::getenv("BH_WALK_PIPE")) c->walk_mode = std::atoi(e);
     if (const char *e = std::getenv("BH_WALK_XCD")) c->walk_xcd = std::atoi(e) != 0;
     if (const char *e = std::getenv("BH_WALK_SPLIT")) c->walk_split = std::atoi(e);
+    if (const char *e = std::getenv("BH_BUILD_ITEMS")) c->build_items = std::atoi(e);
     if (const char *e = std::getenv("BH_SORT_ONESWEEP")) c->sort_onesweep = std::atoi(e) != 0;
     c->hilbert = !c->exact;
     if (const char *e = std::getenv("BH_HILBERT")) c->hilbert = !c->exact && std::atoi(e) != 0;
@@ -401,13 +429,13 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     { char *t; A(&t, cap * 2 * (c->exact ? sizeof(double) : sizeof(float))); c->force = t; }
     A(&c->keys[0], cap); A(&c->keys[1], cap); A(&c->vals[0], cap); A(&c->vals[1], cap);
     A(&c->cnt, cap + 1);
-    { const size_t nbl = blocks_for(cap, kSortTile);
+    { const size_t nbl = std::max<size_t>(blocks_for(cap, kSortTile), blocks_for(std::min<int64_t>(cap, 1 << 22), kBlock * kSmallItems));
       A(&c->radix_counts, (size_t)kRadix * nbl);
       A(&c->bsum_sort, kRadix + 8);
       c->os_status_words = (int64_t)kMaxPasses * nbl * kRadix;
       A(&c->os_status, c->os_status_words); A(&c->os_ghist, kMaxPasses * kRadix); A(&c->os_counter, kMaxPasses);
       A(&c->os_err, 4); }
-    A(&c->bsum_u32, blocks_for(cap + 1, kTile) + 8);
+    A(&c->bsum_u32, std::max<size_t>(blocks_for(cap + 1, kTile), blocks_for(std::min<int64_t>(cap, 1 << 22) + 1, kBlock * kSmallItems)) + 8);
     A(&c->partial, 4 * (std::max<size_t>(1024, blocks_for(cap, kWave)) + 2)); A(&c->box, 4);
     A(&c->ctr, 1);
     if (c->exact) {
@@ -418,7 +446,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
         A(&c->cell_first, c->internal_cap + 1);
         A(&c->coarse, cap / 256 + 2);
         A(&c->spos, cap); A(&c->spos_out, cap + 64 * kBlock + 1024); A(&c->svel, cap + 64 * kBlock + 1024); A(&c->smass, cap);
-        A(&c->terms, cap + 1); A(&c->bsum_d3, blocks_for(cap + 1, kTile) + 8);
+        A(&c->terms, cap + 1); A(&c->bsum_d3, std::max<size_t>(blocks_for(cap + 1, kTile), blocks_for(std::min<int64_t>(cap, 1 << 22) + 1, kBlock * kSmallItems)) + 8);
     }
     if (rc) return bail(rc);
     if (hipMemset(c->os_err, 0, 16) != hipSuccess) { c->err = "hipMemset failed"; return bail(BH_ERR_DEVICE); }

@@ -99,6 +99,9 @@ __global__ __launch_bounds__(kBlock) void radix_rowscan(uint32_t *__restrict__ c
 constexpr int kRadix = 1 << kRadixBits;
 static_assert(kRadix == kBlock, "one thread per digit");
 
+// ITEMS keys per thread: 8 (tiles of 2,048) when there are enough tiles to fill the GPU, 2 (tiles of
+// 512) for launches of few bodies, where a workgroup's 8 sequential rounds are pure latency
+template <int ITEMS>
 __global__ __launch_bounds__(kBlock) void radix_hist(const uint64_t *__restrict__ keys,
                                                       uint32_t *__restrict__ counts, int64_t n,
                                                       int shift, int nblocks)
@@ -106,9 +109,9 @@ __global__ __launch_bounds__(kBlock) void radix_hist(const uint64_t *__restrict_
     __shared__ uint32_t h[kRadix];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * ITEMS);
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = base + r * kBlock + threadIdx.x;
         if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (kRadix - 1)], 1u);
     }
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(kBlock) void radix_hist(const uint64_t *__restrict_
     counts[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
+template <int ITEMS>
 __global__ __launch_bounds__(kBlock) void radix_scatter(const uint64_t *__restrict__ kin,
                                                          const uint32_t *__restrict__ vin,
                                                          uint64_t *__restrict__ kout,
@@ -139,10 +143,10 @@ __global__ __launch_bounds__(kBlock) void radix_scatter(const uint64_t *__restri
     for (int k = 0; k < kWavesPerBlock; ++k) wcnt[k][t] = 0;
     __syncthreads();
 
-    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * ITEMS);
     const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
 #pragma unroll 1
-    for (int r = 0; r < kSortItems; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = base + r * kBlock + t;
         const bool valid = i < n;
         const uint64_t key = valid ? kin[i] : 0ull;

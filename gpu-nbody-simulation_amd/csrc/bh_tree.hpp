@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
 // thread t, so every access is coalesced.  Also produces the tile sums of both scans, so no
 // separate reduction launches are needed.
 // (Real2/Real: the state's type; SReal2/SReal: the type of the sorted copies the walk reads)
-template <bool EXACT, typename Real2, typename Real, typename SReal2 = Real2, typename SReal = Real>
+template <bool EXACT, int ITEMS, typename Real2, typename Real, typename SReal2 = Real2, typename SReal = Real>
 __global__ __launch_bounds__(kBlock) void prep_kernel(const uint64_t *__restrict__ keys,
                                                        const uint32_t *__restrict__ perm,
                                                        const Real2 *__restrict__ pos,
@@ -175,11 +175,11 @@ __global__ __launch_bounds__(kBlock) void prep_kernel(const uint64_t *__restrict
 {
     __shared__ uint32_t smu[kWavesPerBlock + 1];
     __shared__ d3 smd[kWavesPerBlock + 1];
-    const int64_t base = (int64_t)blockIdx.x * kTile;
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * ITEMS);
     uint32_t csum = 0;
     d3 tsum{0.0, 0.0, 0.0};
 #pragma unroll
-    for (int k = 0; k < kItems; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
         const int64_t i = base + k * kBlock + threadIdx.x;
         if (i < n) {
             uint32_t c = 0;
@@ -249,22 +249,41 @@ __global__ __launch_bounds__(kBlock) void scan_top2(uint32_t *__restrict__ bsum_
 }
 
 // per tile: cnt -> exclusive offsets (ranks), fp32: terms -> exclusive prefix sums (n+1 entries);
-// row by row (256 consecutive elements per block scan), so accesses are coalesced
-template <bool EXACT>
+// row by row (256 consecutive elements per block scan), so accesses are coalesced.
+// FOLD: bsum_* hold the raw tile TOTALS written by prep_kernel (at most kBlock of them) and every
+// workgroup sums the tiles before it itself -- one launch less for launches of few bodies, where
+// scan_top2 is nothing but its ~5 us of launch; workgroup 0 publishes the cell count.
+template <bool EXACT, int ITEMS, bool FOLD>
 __global__ __launch_bounds__(kBlock) void scan_apply2(uint32_t *__restrict__ cnt,
                                                        const uint32_t *__restrict__ bsum_u32,
                                                        d3 *__restrict__ terms,
-                                                       const d3 *__restrict__ bsum_d3, int64_t n,
+                                                       const d3 *__restrict__ bsum_d3, int nbs, int64_t n,
                                                        uint32_t *__restrict__ cell_first,
-                                                       int64_t internal_cap)
+                                                       int64_t internal_cap, TreeCounters *ctr)
 {
     __shared__ uint32_t smu[kWavesPerBlock + 1];
     __shared__ d3 smd[kWavesPerBlock + 1];
-    const int64_t base = (int64_t)blockIdx.x * kTile;
-    uint32_t ucarry = bsum_u32[blockIdx.x];
-    d3 dcarry = EXACT ? d3{0.0, 0.0, 0.0} : bsum_d3[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * ITEMS);
+    uint32_t ucarry;
+    d3 dcarry{0.0, 0.0, 0.0};
+    if (FOLD) {
+        const int t = threadIdx.x;
+        const bool before = t < (int)blockIdx.x;
+        const uint32_t v = (t < nbs) ? bsum_u32[t] : 0u;
+        uint32_t uall;
+        (void)block_exclusive_sum(before ? v : 0u, smu, ucarry);
+        (void)block_exclusive_sum(v, smu, uall);
+        if (blockIdx.x == 0 && t == 0) ctr->n_internal = uall;
+        if (!EXACT) {
+            const d3 dv = (t < nbs && before) ? bsum_d3[t] : d3{0.0, 0.0, 0.0};
+            (void)block_exclusive_sum(dv, smd, dcarry);
+        }
+    } else {
+        ucarry = bsum_u32[blockIdx.x];
+        if (!EXACT) dcarry = bsum_d3[blockIdx.x];
+    }
 #pragma unroll 1
-    for (int k = 0; k < kItems; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
         const int64_t i = base + k * kBlock + threadIdx.x;
         const uint32_t v = (i < n) ? cnt[i] : 0u;
         uint32_t utot;
@@ -275,8 +294,8 @@ __global__ __launch_bounds__(kBlock) void scan_apply2(uint32_t *__restrict__ cnt
             // rank -> first body of the cell: lets the node kernel run one thread per CELL (the
             // body that starts a whole chain of nested cells would otherwise process them serially)
             if (!EXACT)
-                for (uint32_t k = 0; k < v; ++k)
-                    if ((int64_t)(r0 + k) < internal_cap) cell_first[r0 + k] = (uint32_t)i;
+                for (uint32_t j = 0; j < v; ++j)
+                    if ((int64_t)(r0 + j) < internal_cap) cell_first[r0 + j] = (uint32_t)i;
         }
         ucarry += utot;
         if (!EXACT) {
