@@ -228,7 +228,7 @@ int enqueue_build_t(bh_ctx *c)
         hipLaunchKernelGGL((prep_kernel<EXACT, ITEMS, Real2, Real, SReal2, SReal>), dim3(nbs), dim3(kBlock), 0, st,
                            c->keys_sorted, c->perm, pos, mass, c->cnt, c->bsum_u32, (SReal2 *)c->spos,
                            (SReal *)c->smass, c->terms, c->bsum_d3, c->coarse, n, Dm);
-        if (nbs <= (unsigned)kBlock) {
+        if (nbs <= 4u * kBlock) {
             // few tiles: every workgroup sums the tile totals before it itself (no scan_top2 launch)
             hipLaunchKernelGGL((scan_apply2<EXACT, ITEMS, true>), dim3(nbs), dim3(kBlock), 0, st, c->cnt, c->bsum_u32,
                                c->terms, c->bsum_d3, (int)nbs, n, c->cell_first, c->internal_cap, c->ctr);

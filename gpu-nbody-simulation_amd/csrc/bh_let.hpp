@@ -36,6 +36,7 @@ namespace bh {
 constexpr int kMaxWorld = 64;
 constexpr int kLetBoxes = 8;       // bounding boxes per rank
 constexpr int kLetBoxParts = 16;   // first step: partial blocks per box
+static_assert(kMaxWorld <= kWave, "let_box_kernel clears one counter per lane");
 
 struct LetCounters {
     uint32_t count[kMaxWorld];   // quads packed for each peer
@@ -44,17 +45,20 @@ struct LetCounters {
 };
 
 // all_bounds: (world * kLetBoxes) x {xmin, xmax, ymin, ymax} raw (unpadded) bounds of slices of every
-// rank's bodies.  One thread: global box with the reference's padding (project.cu:553-570).
-__global__ void let_box_kernel(const double *__restrict__ all_bounds, int nboxes, double *__restrict__ box,
-                               TreeCounters *ctr, LetCounters *lc)
+// rank's bodies.  One wave: global box with the reference's padding (project.cu:553-570).
+__global__ __launch_bounds__(kWave) void let_box_kernel(const double *__restrict__ all_bounds, int nboxes,
+                                                         double *__restrict__ box, TreeCounters *ctr, LetCounters *lc)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
     double xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
-    for (int r = 0; r < nboxes; ++r) {
+    for (int r = threadIdx.x; r < nboxes; r += kWave) {
         const double a = all_bounds[4 * r], b = all_bounds[4 * r + 1], c = all_bounds[4 * r + 2], d = all_bounds[4 * r + 3];
         xlo = (a < xlo) ? a : xlo;  xhi = (xhi < b) ? b : xhi;
         ylo = (c < ylo) ? c : ylo;  yhi = (yhi < d) ? d : yhi;
     }
+    xlo = wave_min(xlo); xhi = wave_max(xhi); ylo = wave_min(ylo); yhi = wave_max(yhi);
+    if (threadIdx.x < kMaxWorld) lc->count[threadIdx.x] = 0;
+    if (threadIdx.x != 0) return;
     const double ex = xhi - xlo, ey = yhi - ylo;
     const double span = (ex < ey) ? ey : ex;
     double pad = 0.1 * span;
@@ -62,7 +66,6 @@ __global__ void let_box_kernel(const double *__restrict__ all_bounds, int nboxes
     box[0] = xlo - pad; box[1] = xhi + pad; box[2] = ylo - pad; box[3] = yhi + pad;
     ctr->n_internal = 0; ctr->overflow = 0;
     ctr->visits = 0; ctr->interactions = 0; ctr->wave_nodes = 0;
-    for (int r = 0; r < kMaxWorld; ++r) lc->count[r] = 0;
     lc->overflow = 0;
 }
 
@@ -123,11 +126,21 @@ __global__ __launch_bounds__(kBlock) void let_mark_kernel(const QuadF *__restric
                                                            int64_t internal_cap, uint64_t *__restrict__ needmask)
 {
     __shared__ float sbox[kMaxWorld * kLetBoxes][4];
+    __shared__ float sall[kMaxWorld][4];                     // a peer's boxes taken together: a cheap first test
     for (int i = threadIdx.x; i < world * kLetBoxes; i += kBlock) {
         // outward-rounded float copies of the peers' boxes (the test must stay conservative)
         const double *b = all_bounds + 4 * i;
         sbox[i][0] = __double2float_rd(b[0]); sbox[i][1] = __double2float_ru(b[1]);
         sbox[i][2] = __double2float_rd(b[2]); sbox[i][3] = __double2float_ru(b[3]);
+    }
+    __syncthreads();
+    if (threadIdx.x < world) {
+        float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+        for (int b = 0; b < kLetBoxes; ++b) {
+            const float *bx = sbox[threadIdx.x * kLetBoxes + b];
+            x0 = fminf(x0, bx[0]); x1 = fmaxf(x1, bx[1]); y0 = fminf(y0, bx[2]); y1 = fmaxf(y1, bx[3]);
+        }
+        sall[threadIdx.x][0] = x0; sall[threadIdx.x][1] = x1; sall[threadIdx.x][2] = y0; sall[threadIdx.x][3] = y1;
     }
     __syncthreads();
     const uint32_t total = ctr->n_internal;
@@ -146,6 +159,11 @@ __global__ __launch_bounds__(kBlock) void let_mark_kernel(const QuadF *__restric
         uint64_t mask = 0;
         for (int p = 0; p < world; ++p) {
             if (p == rank) continue;
+            {
+                const float dx = fmaxf(fmaxf(sall[p][0] - cx, cx - sall[p][1]), 0.f);
+                const float dy = fmaxf(fmaxf(sall[p][2] - cy, cy - sall[p][3]), 0.f);
+                if (!(dx * dx + dy * dy <= thr)) continue;     // out of reach of everything peer p holds
+            }
             bool near = false;
 #pragma unroll
             for (int b = 0; b < kLetBoxes; ++b) {
@@ -160,29 +178,59 @@ __global__ __launch_bounds__(kBlock) void let_mark_kernel(const QuadF *__restric
     }
 }
 
-// per (peer, tile): number of needed quads in the tile
+// per (peer, tile): number of needed quads in the tile.  A thread owns kItems CONSECUTIVE quads, so its
+// count per peer is at most kItems and a tile's at most kTile = 2,048: four peers' counts travel in
+// the 16-bit fields of one 64-bit word and one block reduction serves four peers.
+__device__ __forceinline__ uint64_t let_packed_counts(const uint64_t (&m)[kItems], int p0)
+{
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < kItems; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c += ((m[j] >> (p0 + q)) & 1ull) << (16 * q);
+    return c;
+}
+
+__device__ __forceinline__ uint64_t block_exclusive_sum_u64(uint64_t v, uint64_t *smem, uint64_t &total)
+{
+    uint64_t inc = v;
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint64_t o = __shfl_up(inc, d, kWave);
+        if (l >= d) inc += o;
+    }
+    if (l == kWave - 1) smem[wave_id()] = inc;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+        const uint64_t s = smem[w];
+        if (w < wave_id()) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
 __global__ __launch_bounds__(kBlock) void let_count_kernel(const uint64_t *__restrict__ needmask, int world,
                                                             const TreeCounters *__restrict__ ctr,
                                                             int64_t internal_cap, uint32_t *__restrict__ tsum,
                                                             int ntiles)
 {
-    __shared__ uint32_t sm[kWavesPerBlock + 1];
+    __shared__ uint64_t sm[kWavesPerBlock + 1];
     const uint32_t total = ctr->n_internal;
     const int64_t nq = ((int64_t)total > internal_cap) ? 0 : (int64_t)total + 1;
-    const int64_t base = (int64_t)blockIdx.x * kTile;
+    const int64_t first = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kItems;
     uint64_t m[kItems];
 #pragma unroll
-    for (int j = 0; j < kItems; ++j) {
-        const int64_t k = base + j * kBlock + threadIdx.x;
-        m[j] = (k < nq) ? needmask[k] : 0ull;
-    }
-    for (int p = 0; p < world; ++p) {
-        uint32_t c = 0;
-#pragma unroll
-        for (int j = 0; j < kItems; ++j) c += (uint32_t)((m[j] >> p) & 1ull);
-        uint32_t tot;
-        (void)block_exclusive_sum(c, sm, tot);
-        if (threadIdx.x == 0) tsum[(int64_t)p * ntiles + blockIdx.x] = tot;
+    for (int j = 0; j < kItems; ++j) m[j] = (first + j < nq) ? needmask[first + j] : 0ull;
+    for (int p0 = 0; p0 < world; p0 += 4) {
+        uint64_t tot;
+        (void)block_exclusive_sum_u64(let_packed_counts(m, p0), sm, tot);
+        if (threadIdx.x < 4 && p0 + (int)threadIdx.x < world)
+            tsum[(int64_t)(p0 + threadIdx.x) * ntiles + blockIdx.x] = (uint32_t)((tot >> (16 * threadIdx.x)) & 0xFFFFull);
     }
 }
 
@@ -207,27 +255,32 @@ __global__ __launch_bounds__(kBlock) void let_rowscan_kernel(uint32_t *__restric
     }
 }
 
-// outidx[peer][quad] = rank of the quad among the peer's needed quads (row by row: coalesced)
+// outidx[peer][quad] = rank of the quad among the peer's needed quads (same blocked layout and packed
+// counters as let_count_kernel: world/4 block scans per tile instead of world * kItems)
 __global__ __launch_bounds__(kBlock) void let_apply_kernel(const uint64_t *__restrict__ needmask, int world,
                                                             const TreeCounters *__restrict__ ctr,
                                                             int64_t internal_cap, const uint32_t *__restrict__ tsum,
                                                             int ntiles, uint32_t *__restrict__ outidx,
                                                             int64_t outidx_stride)
 {
-    __shared__ uint32_t sm[kWavesPerBlock + 1];
+    __shared__ uint64_t sm[kWavesPerBlock + 1];
     const uint32_t total = ctr->n_internal;
     const int64_t nq = ((int64_t)total > internal_cap) ? 0 : (int64_t)total + 1;
-    const int64_t base = (int64_t)blockIdx.x * kTile;
-    for (int p = 0; p < world; ++p) {
-        uint32_t carry = tsum[(int64_t)p * ntiles + blockIdx.x];
-#pragma unroll 1
-        for (int j = 0; j < kItems; ++j) {
-            const int64_t k = base + j * kBlock + threadIdx.x;
-            const uint32_t bit = (k < nq) ? (uint32_t)((needmask[k] >> p) & 1ull) : 0u;
-            uint32_t tot;
-            const uint32_t ex = block_exclusive_sum(bit, sm, tot);
-            if (bit) outidx[(int64_t)p * outidx_stride + k] = carry + ex;
-            carry += tot;
+    const int64_t first = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kItems;
+    uint64_t m[kItems];
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) m[j] = (first + j < nq) ? needmask[first + j] : 0ull;
+    for (int p0 = 0; p0 < world; p0 += 4) {
+        uint64_t tot;
+        const uint64_t ex = block_exclusive_sum_u64(let_packed_counts(m, p0), sm, tot);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = p0 + q;
+            if (p >= world) break;
+            uint32_t o = tsum[(int64_t)p * ntiles + blockIdx.x] + (uint32_t)((ex >> (16 * q)) & 0xFFFFull);
+#pragma unroll
+            for (int j = 0; j < kItems; ++j)
+                if ((m[j] >> p) & 1ull) outidx[(int64_t)p * outidx_stride + first + j] = o++;
         }
     }
 }

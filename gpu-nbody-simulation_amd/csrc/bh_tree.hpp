@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void scan_top2(uint32_t *__restrict__ bsum_
 
 // per tile: cnt -> exclusive offsets (ranks), fp32: terms -> exclusive prefix sums (n+1 entries);
 // row by row (256 consecutive elements per block scan), so accesses are coalesced.
-// FOLD: bsum_* hold the raw tile TOTALS written by prep_kernel (at most kBlock of them) and every
+// FOLD: bsum_* hold the raw tile TOTALS written by prep_kernel (at most 4 * kBlock of them) and every
 // workgroup sums the tiles before it itself -- one launch less for launches of few bodies, where
 // scan_top2 is nothing but its ~5 us of launch; workgroup 0 publishes the cell count.
 template <bool EXACT, int ITEMS, bool FOLD>
@@ -267,17 +267,22 @@ __global__ __launch_bounds__(kBlock) void scan_apply2(uint32_t *__restrict__ cnt
     uint32_t ucarry;
     d3 dcarry{0.0, 0.0, 0.0};
     if (FOLD) {
-        const int t = threadIdx.x;
-        const bool before = t < (int)blockIdx.x;
-        const uint32_t v = (t < nbs) ? bsum_u32[t] : 0u;
-        uint32_t uall;
-        (void)block_exclusive_sum(before ? v : 0u, smu, ucarry);
-        (void)block_exclusive_sum(v, smu, uall);
-        if (blockIdx.x == 0 && t == 0) ctr->n_internal = uall;
-        if (!EXACT) {
-            const d3 dv = (t < nbs && before) ? bsum_d3[t] : d3{0.0, 0.0, 0.0};
-            (void)block_exclusive_sum(dv, smd, dcarry);
+        // thread t holds the tiles t, t + 256, ...: a fixed summation tree, the same for every workgroup
+        uint32_t vb = 0, va = 0;
+        d3 db{0.0, 0.0, 0.0};
+        for (int t = threadIdx.x; t < nbs; t += kBlock) {
+            const uint32_t v = bsum_u32[t];
+            va += v;
+            if (t < (int)blockIdx.x) {
+                vb += v;
+                if (!EXACT) db += bsum_d3[t];
+            }
         }
+        uint32_t uall;
+        (void)block_exclusive_sum(vb, smu, ucarry);
+        (void)block_exclusive_sum(va, smu, uall);
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_internal = uall;
+        if (!EXACT) (void)block_exclusive_sum(db, smd, dcarry);
     } else {
         ucarry = bsum_u32[blockIdx.x];
         if (!EXACT) dcarry = bsum_d3[blockIdx.x];
