@@ -542,8 +542,13 @@ __global__ __launch_bounds__(kBlock, 4) void nodes_fast_kernel(
     const uint32_t r_block = blockIdx.x * kBlock;
     if (r_block >= total) return;                               // uniform per workgroup
 
+    // this thread's cell: issue its two loads now, they do not depend on the key window below
+    const uint32_t r = r_block + threadIdx.x;
+    const int32_t i_pre = (r < total) ? (int32_t)cell_first[r] : 0;
+    const uint32_t off_pre = (r < total) ? off[i_pre] : 0u;
+
     // key window starting one body before the first cell of this workgroup
-    if (threadIdx.x == 0) s_wlo = (int32_t)cell_first[r_block] - 1;
+    if (threadIdx.x == 0) s_wlo = i_pre - 1;
     __syncthreads();
     const int32_t wlo = s_wlo;
     for (int k = threadIdx.x; k < kKeyWin; k += kBlock) {
@@ -571,12 +576,11 @@ __global__ __launch_bounds__(kBlock, 4) void nodes_fast_kernel(
         return lo;
     };
 
-    const uint32_t r = r_block + threadIdx.x;
     if (r < total) {
-    const int32_t i = (int32_t)cell_first[r];
+    const int32_t i = i_pre;
     const uint64_t key = K(i);
     const int Lp = (i == 0) ? -1 : shared_levels(K(i - 1), key, Dm);
-    const int d = Lp + 1 + (int)(r - off[i]);                   // this cell's depth
+    const int d = Lp + 1 + (int)(r - off_pre);                  // this cell's depth
 
     const double ex0 = box[1] - box[0], ey0 = box[3] - box[2];
     const double q0 = ((ex0 > ey0) ? ex0 : ey0) / theta;       // size/theta at depth 0
@@ -613,29 +617,46 @@ __global__ __launch_bounds__(kBlock, 4) void nodes_fast_kernel(
     // (size/theta)^2 of the children (depth d+1): exact power-of-four scaling
     const float thr_child = (float)ldexp(thr0, -2 * (d + 1));
 
-    int32_t bc = i;
+    // child boundaries first, then every global load of the four children at once: the loads are
+    // independent of each other, and this kernel's time is the length of its per-thread chain of
+    // dependent memory accesses (3 rounds of resident workgroups x one chain at N = 1M)
+    int32_t bnd[5];
+    bnd[0] = i; bnd[4] = e;
+    for (int c = 1; c < 4; ++c) bnd[c] = lower_bound(bnd[c - 1], e, shc, (pfx << 2) | (uint64_t)c);
+    d3 ps[5];
+    uint32_t offc[4];
+    uint64_t kprev[4], kcur[4];
+    float2 p1[4];
+    float m1[4];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) ps[c] = psum[bnd[c]];
+#pragma unroll
     for (int c = 0; c < 4; ++c) {
-        int32_t bn;                                              // first body of the next child
-        if (c == 3) bn = e;
-        else {
-            const uint64_t target = (pfx << 2) | (uint64_t)(c + 1);
-            bn = lower_bound(bc, e, shc, target);
-        }
+        const int32_t bc = bnd[c];
+        const bool some = bnd[c + 1] > bc;
+        offc[c] = some ? off[bc] : 0u;
+        kcur[c] = some ? K(bc) : 0ull;
+        kprev[c] = (some && bc > 0) ? K(bc - 1) : 0ull;
+        p1[c] = some ? spos[bc] : float2{0.f, 0.f};
+        m1[c] = some ? smass[bc] : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int32_t bc = bnd[c], bn = bnd[c + 1];
         const int32_t nc = bn - bc;
         float cx = 0.f, cy = 0.f, m = 0.f, thr = 0.f;            // leaves: thr = 0 (see the walk)
         int32_t child = -1;
         if (nc == 1) {
-            const float2 p = spos[bc];
-            cx = p.x; cy = p.y; m = smass[bc];
+            cx = p1[c].x; cy = p1[c].y; m = m1[c];
         } else if (nc > 1) {
-            const d3 lo_s = psum[bc], hi_s = psum[bn];
+            const d3 lo_s = ps[c], hi_s = ps[c + 1];
             const double mm = hi_s.a - lo_s.a;
             m = (float)mm; cx = (float)((hi_s.b - lo_s.b) / mm); cy = (float)((hi_s.c - lo_s.c) / mm);
             if (d + 1 == Dm) {                                   // depth-cap cell
                 if (!COMPAT && nc <= kMaxBucket) { thr = INFINITY; child = -(4 * quad + c) - 2; }
             } else {                                             // subdivided cell
-                const int Lpc = (bc == 0) ? -1 : shared_levels(K(bc - 1), K(bc), Dm);
-                child = (int32_t)(off[bc] + (uint32_t)((d + 1) - (Lpc + 1))) + 1;
+                const int Lpc = (bc == 0) ? -1 : shared_levels(kprev[c], kcur[c], Dm);
+                child = (int32_t)(offc[c] + (uint32_t)((d + 1) - (Lpc + 1))) + 1;
                 thr = thr_child;
             }
         }
@@ -643,7 +664,6 @@ __global__ __launch_bounds__(kBlock, 4) void nodes_fast_kernel(
         put_lds(c, cx, cy, m, thr, child);
         stage_a[threadIdx.x * 8 + 2 * c] = bc;
         stage_a[threadIdx.x * 8 + 2 * c + 1] = nc;
-        bc = bn;
     }
     }   // r < total
 
