@@ -486,7 +486,7 @@ constexpr int kKeyHalo = 768;
 constexpr int kKeyWin = kBlock + 1 + kKeyHalo;
 
 template <bool COMPAT>
-__global__ __launch_bounds__(kBlock, 4) void nodes_fast_kernel(
+__global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     const uint64_t *__restrict__ keys, const uint64_t *__restrict__ coarse,
     const uint32_t *__restrict__ off, const uint32_t *__restrict__ cell_first,
     const float2 *__restrict__ spos,
@@ -496,14 +496,18 @@ __global__ __launch_bounds__(kBlock, 4) void nodes_fast_kernel(
 {
     // ONE THREAD PER SUBDIVIDED CELL (rank r): its first body comes from cell_first[r], its depth
     // from its position in that body's chain.  32-bit indices throughout (bh_create caps n < 2^31).
-    __shared__ uint64_t wkeys[kKeyWin];
+    // LDS is used twice: first as the key window of the searches, then -- after a barrier -- as the
+    // staging area of the quads (28 KB instead of 36 KB per workgroup: 5 resident workgroups per CU)
+    constexpr int kStageBytes = kBlock * 28 * 4, kWinBytes = kKeyWin * 8;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kStageBytes > kWinBytes ? kStageBytes : kWinBytes];
+    uint64_t *wkeys = reinterpret_cast<uint64_t *>(lds_raw);
     __shared__ int32_t s_wlo;
     // The 256 quads of a workgroup are contiguous in memory (quad = rank + 1): they are assembled
     // in LDS and written out with coalesced 16-byte stores.  Storing field by field from the
     // owning lanes costs 24 scattered 4-byte stores per cell -- 18 M separate L2 write requests at
     // N = 1M, which was most of this kernel's time.
-    __shared__ __attribute__((aligned(16))) int32_t stage_q[kBlock * 20];
-    __shared__ __attribute__((aligned(16))) int32_t stage_a[kBlock * 8];
+    int32_t *stage_q = reinterpret_cast<int32_t *>(lds_raw);             // kBlock * 20 dwords
+    int32_t *stage_a = stage_q + kBlock * 20;                            // kBlock * 8 dwords
     const int32_t n = (int32_t)n64;
     const uint32_t total = ctr->n_internal;
     float *qw = reinterpret_cast<float *>(qf);                  // 20 dwords per quad
@@ -576,6 +580,8 @@ __global__ __launch_bounds__(kBlock, 4) void nodes_fast_kernel(
         return lo;
     };
 
+    float res_cx[4], res_cy[4], res_m[4], res_thr[4];
+    int32_t res_child[4], res_bc[4], res_nc[4];
     if (r < total) {
     const int32_t i = i_pre;
     const uint64_t key = K(i);
@@ -661,12 +667,20 @@ __global__ __launch_bounds__(kBlock, 4) void nodes_fast_kernel(
             }
         }
         if (!(m > 1e-15f)) { cx = 0.f; cy = 0.f; m = 0.f; thr = 0.f; child = -1; }   // project.cu:617
-        put_lds(c, cx, cy, m, thr, child);
-        stage_a[threadIdx.x * 8 + 2 * c] = bc;
-        stage_a[threadIdx.x * 8 + 2 * c + 1] = nc;
+        res_cx[c] = cx; res_cy[c] = cy; res_m[c] = m; res_thr[c] = thr; res_child[c] = child;
+        res_bc[c] = bc; res_nc[c] = nc;
     }
     }   // r < total
 
+    __syncthreads();                                            // the key window is dead from here on
+    if (r < total) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            put_lds(c, res_cx[c], res_cy[c], res_m[c], res_thr[c], res_child[c]);
+            stage_a[threadIdx.x * 8 + 2 * c] = res_bc[c];
+            stage_a[threadIdx.x * 8 + 2 * c + 1] = res_nc[c];
+        }
+    }
     // coalesced write-out of this workgroup's quads [r_block + 1, r_block + 1 + cells)
     __syncthreads();
     const uint32_t cells = (total - r_block < (uint32_t)kBlock) ? total - r_block : (uint32_t)kBlock;
