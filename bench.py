@@ -55,6 +55,9 @@ def parse():
                     help="multi-GPU scheme (DESIGN.md 9): 'let' = ORB partition, local trees, locally-"
                          "essential-tree exchange (bodies live on one rank only); 'replicated' = every rank "
                          "builds the whole tree and walks a share, one all_gather per step")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: rehearsal only (collectives staged through the host; lets several ranks "
+                         "share one GPU together with BHGPU_REHEARSE_ON_DEVICE)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="take the multi-GPU exchange path (step_local, all_gather, scatter) even on one rank")
     ap.add_argument("--cpu-sample", type=int, default=0,
@@ -116,7 +119,7 @@ def main():
                                                       partition_orb)
     from gpu_nbody_simulation_amd.engine import FLAG_LDS_STACK, FLAG_WALK_STATS
 
-    rank, local, world = init_process_group_from_env("nccl")
+    rank, local, world = init_process_group_from_env(a.backend)
     if a.force_sharded and world == 1 and not dist.is_initialized() and "RANK" in os.environ:
         dist.init_process_group(backend="nccl", rank=0, world_size=1)
     if world != a.gpus:
@@ -126,6 +129,9 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if "BHGPU_REHEARSE_ON_DEVICE" in os.environ:
+        # rehearsal aid: several ranks on ONE device (only where the collective library allows it)
+        local = int(os.environ["BHGPU_REHEARSE_ON_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -174,7 +180,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if use_let:

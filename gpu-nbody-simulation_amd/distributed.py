@@ -225,10 +225,21 @@ class LetStepper:
             self.send = wrap_device(sd, self.world * nb, "|u1", self.device)
             self.recv = wrap_device(rv, self.world * nb, "|u1", self.device)
 
+    def _staged(self) -> bool:
+        """Device buffers but a host-only backend (gloo): stage the collectives through the host.  Only
+        for rehearsing the multi-rank logic where RCCL cannot run (several ranks on one GPU)."""
+        return self.lbounds.is_cuda and dist.is_initialized() and dist.get_backend() == "gloo"
+
     def _exchange_bounds(self) -> None:
         self.eng.let_bounds()
         if dist.is_initialized() and self.world > 1:
-            dist.all_gather_into_tensor(self.all_bounds, self.lbounds.clone())
+            if self._staged():
+                self.eng.sync()
+                out = torch.empty(self.all_bounds.numel(), dtype=self.all_bounds.dtype)
+                dist.all_gather_into_tensor(out, self.lbounds.cpu())
+                self.all_bounds.copy_(out)
+            else:
+                dist.all_gather_into_tensor(self.all_bounds, self.lbounds.clone())
         else:
             assert self.world == 1
             self.all_bounds.copy_(self.lbounds)
@@ -236,7 +247,12 @@ class LetStepper:
     def step(self, integrate: bool = True) -> None:
         self._exchange_bounds()
         self.eng.let_build()
-        if dist.is_initialized():
+        if dist.is_initialized() and self._staged():
+            self.eng.sync()
+            out = torch.empty(self.recv.numel(), dtype=self.recv.dtype)
+            dist.all_to_all_single(out, self.send.cpu())
+            self.recv.copy_(out)
+        elif dist.is_initialized():
             dist.all_to_all_single(self.recv, self.send)     # block q of send -> block rank of q's recv
         if integrate:
             self.eng.let_walk()
@@ -246,7 +262,8 @@ class LetStepper:
     def max_count(self):
         """(largest LET any rank packed in its last build, whether any overflowed) -- synchronises."""
         counts, ov = self.eng.let_counts(with_overflow=True)
-        t = torch.tensor([max(counts), int(ov)], dtype=torch.int64, device=self.lbounds.device)
+        t = torch.tensor([max(counts), int(ov)], dtype=torch.int64,
+                         device="cpu" if self._staged() else self.lbounds.device)
         if dist.is_initialized() and self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return int(t[0].item()), bool(t[1].item())

@@ -73,14 +73,44 @@ def test_bench_exchange_path_on_real_rccl_single_rank(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1",
-           "--steps", "3", "--warmup", "1", "--n-bodies", "65536", "--max-depth", "16", "--force-sharded",
-           "--no-cpu-baseline", "--no-secondary"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for port, decomposition in ((29533, "replicated"), (29534, "let")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1",
+               "--steps", "3", "--warmup", "1", "--n-bodies", "65536", "--max-depth", "16", "--force-sharded",
+               "--decomposition", decomposition, "--no-cpu-baseline", "--no-secondary"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        assert d["n_gpus"] == 1 and d["value"] > 1e6 and 1 + 4 * 40000 < d["n_nodes"] < 4 * 65536
+        assert 150 < d["interactions_per_body"] < 400
+
+
+def test_bench_let_path_with_three_ranks_sharing_the_gpu(tmp_path):
+    """The whole multi-rank LET path of bench.py -- ORB partition, autotune, bounds all_gather, LET
+    all_to_all, forest walk, overflow check, gathering the final state -- with THREE processes on this
+    one GPU.  RCCL refuses ranks that share a device, so the collectives are staged through the host
+    over gloo (`--backend gloo`); the RCCL calls themselves are covered at world size 1 above."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--n-bodies", "65536",
+            "--no-cpu-baseline", "--no-secondary"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BHGPU_REHEARSE_ON_DEVICE="0")
+    r1 = subprocess.run([sys.executable] + base, capture_output=True, text=True, timeout=600, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+           "--master-addr", "127.0.0.1", "--master-port", "29535"] + base + ["--gpus", "3", "--backend", "gloo"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 1 and d["value"] > 1e6 and 1 + 4 * 40000 < d["n_nodes"] < 4 * 65536
-    assert 150 < d["interactions_per_body"] < 400
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 3 and d["config"]["parallelism"].startswith("orb x3")
+    assert 0 < d["let"]["largest_let_quads"] <= d["let"]["let_cap_quads"]
+    assert 20000 < d["let"]["bodies_on_rank0"] < 24000
+    # the state gathered from the three ranks after 4 steps is the state one GPU reaches
+    assert abs(d["n_nodes"] - one["n_nodes"]) <= 0.001 * one["n_nodes"]
+    assert abs(d["interactions_per_body"] - one["interactions_per_body"]) <= 1e-3 * one["interactions_per_body"]
