@@ -55,6 +55,8 @@ def parse():
                     help="multi-GPU scheme (DESIGN.md 9): 'let' = ORB partition, local trees, locally-"
                          "essential-tree exchange (bodies live on one rank only); 'replicated' = every rank "
                          "builds the whole tree and walks a share, one all_gather per step")
+    ap.add_argument("--let-overlap", action="store_true",
+                    help="LET decomposition: walk the local tree while the all_to_all is in flight")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearsal only (collectives staged through the host; lets several ranks "
                          "share one GPU together with BHGPU_REHEARSE_ON_DEVICE)")
@@ -156,7 +158,7 @@ def main():
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
     if use_let:
         eng.upload(pos[mine], vel[mine], mass[mine])  # this rank's bodies, resident in HBM from here on
-        stepper = LetStepper(eng, rank, world, let_cap=1 << 14, device=dev)
+        stepper = LetStepper(eng, rank, world, let_cap=1 << 14, device=dev, overlap=a.let_overlap)
         cap = stepper.autotune()                      # block size from the measured LET sizes (untimed)
     else:
         eng.upload(pos, vel, mass)                    # bodies resident in HBM from here on
@@ -245,7 +247,7 @@ def main():
             "config": {"workload": f"{a.init}_N{n}_theta{a.theta}", "n_bodies": n, "theta": a.theta,
                        "max_depth": a.max_depth, "init": a.init, "seed": a.seed,
                        "parallelism": "1 GPU" if not sharded else
-                       (f"orb x{world}, local trees + LET all_to_all/step" if use_let
+                       (f"orb x{world}, local trees + LET all_to_all/step" + (" (overlapped)" if a.let_overlap else "") if use_let
                         else f"replicated build, hilbert-range walk x{world}, all_gather/step")},
             "minteractions_per_s": ss.interactions * a.steps / elapsed / 1e6,
             "interactions_per_body": ss.interactions / n,

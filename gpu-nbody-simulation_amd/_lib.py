@@ -83,6 +83,8 @@ SIGNATURES = {
     "bh_let_build": (C.c_int, [_ctx]),
     "bh_let_walk": (C.c_int, [_ctx]),
     "bh_let_forces": (C.c_int, [_ctx]),
+    "bh_let_walk_local": (C.c_int, [_ctx]),
+    "bh_let_walk_remote": (C.c_int, [_ctx, C.c_int32]),
     "bh_let_counts": (C.c_int, [_ctx, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
 }
 

@@ -85,6 +85,7 @@ struct bh_ctx {
     uint32_t *let_tsum = nullptr, *let_outidx = nullptr;
     QuadF *let_send = nullptr;
     double *lbounds = nullptr, *all_bounds = nullptr;
+    float2 *acc_part = nullptr;    // LET mode: raw sums of the local-tree walk (bh_let_walk_local)
     LetCounters *let_ctr = nullptr;
 
     // measurement
@@ -294,7 +295,7 @@ int enqueue_build(bh_ctx *c)
     }
 }
 
-int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted)
+int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
 {
     int64_t lo, hi;
     owned_range(c, &lo, &hi);
@@ -325,6 +326,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted)
         a.lo = lo; a.hi = hi; a.G = (float)c->cfg.G; a.dt = (float)c->cfg.dt;
         a.integrate = integrate ? 1 : 0; a.to_sorted = to_sorted ? 1 : 0;
         a.n_trees = c->let_mode ? c->world : 0; a.self_rank = c->let_mode ? c->rank : -1;
+        a.part = part; a.acc_part = c->acc_part;
         a.forest_base = c->quads_local; a.let_cap = c->let_cap;
         // the register-lane stack holds 64 entries; the walk never needs more than 3*Dm + 2
         const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0 || (3 * c->Dm + 2 > kWave);
@@ -931,6 +933,7 @@ int bh_let_configure(bh_ctx *c, int32_t rank, int32_t world, int64_t let_cap)
         A(&c->let_tsum, (size_t)world * ntiles);
         A(&c->let_outidx, (size_t)world * c->quads_local);
         A(&c->lbounds, 4 * kLetBoxes); A(&c->all_bounds, 4 * kLetBoxes * (size_t)world);
+        A(&c->acc_part, (size_t)std::max<int64_t>(c->cfg.capacity, 1));
         A(&c->let_ctr, 1);
     }
     c->let_cap = let_cap;
@@ -1014,6 +1017,28 @@ int bh_let_walk(bh_ctx *c)
     int rc = enqueue_walk(c, true, false);
     if (rc) return rc;
     c->steps_done += 1;
+    return BH_OK;
+}
+
+// The forest walk in two launches, so that the all_to_all of the LETs can run under the first:
+// bh_let_walk_local needs only bh_let_build's local tree; bh_let_walk_remote needs the received
+// blocks, adds their contribution and finishes the step (integrate != 0) or just the forces.
+int bh_let_walk_local(bh_ctx *c)
+{
+    if (!c || !c->let_mode) return fail(c, BH_ERR_STATE, "bh_let_walk_local: call bh_let_configure first");
+    if (!c->tree_valid) return fail(c, BH_ERR_STATE, "bh_let_walk_local before bh_let_build");
+    BH_HIP(c, hipSetDevice(c->device));
+    return enqueue_walk(c, false, false, 1);
+}
+
+int bh_let_walk_remote(bh_ctx *c, int32_t integrate)
+{
+    if (!c || !c->let_mode) return fail(c, BH_ERR_STATE, "bh_let_walk_remote: call bh_let_configure first");
+    if (!c->tree_valid) return fail(c, BH_ERR_STATE, "bh_let_walk_remote before bh_let_build");
+    BH_HIP(c, hipSetDevice(c->device));
+    int rc = enqueue_walk(c, integrate != 0, false, 2);
+    if (rc) return rc;
+    if (integrate) c->steps_done += 1;
     return BH_OK;
 }
 

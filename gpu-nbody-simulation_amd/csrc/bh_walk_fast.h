@@ -33,6 +33,11 @@ struct WalkFastArgs {
     // locally-essential trees received from the peers, whose root quads sit at
     // forest_base + t * let_cap for every t != self_rank, t < n_trees.  n_trees == 0: local tree only.
     int32_t n_trees, self_rank;
+    // part: 0 = the whole forest in one launch; 1 = the local tree only, raw sums parked in acc_part
+    // (sorted order), nothing else written; 2 = the received LETs only, continuing from acc_part, then
+    // the usual epilogue.  Lets the LET all_to_all overlap the local walk.
+    int32_t part;
+    float2 *acc_part;
     int64_t forest_base, let_cap;
 };
 

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
     const float2 p = valid ? a.spos[s] : float2{0.f, 0.f};
     asm volatile("" ::"v"(p.x), "v"(p.y));                // take the one-time vmcnt wait here, not per child
     float ax = 0.f, ay = 0.f;
+    if (a.part == 2 && valid && (SPLIT == 1 || w == 0)) { const float2 t = a.acc_part[s]; ax = t.x; ay = t.y; }
     unsigned long long n_vis = 0, n_int = 0, n_wave = 0;
 
     const QuadF BH_CONSTANT *quads = as_constant(a.quads);
@@ -213,11 +214,13 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
     if (SPLIT > 1) {
         const uint64_t everyone = __ballot(valid);
         // level 0: the root quad of the local tree and of every received LET (at most 57 entries)
-        int F = 1 + ((a.n_trees > 0) ? a.n_trees - 1 : 0);
+        const int n_remote = (a.n_trees > 0 && a.part != 1) ? a.n_trees - 1 : 0;
+        const int n_local = (a.part != 2) ? 1 : 0;
+        int F = n_local + n_remote;
         if (w == 0 && lane < F) {
             int32_t base = 0;
-            if (lane > 0) {
-                int32_t t = lane - 1;
+            if (lane >= n_local) {
+                int32_t t = lane - n_local;
                 if (t >= a.self_rank) ++t;                      // the peers in rank order, self skipped
                 base = (int32_t)(a.forest_base + (int64_t)t * a.let_cap);
             }
@@ -352,7 +355,8 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
         // the local tree, then (distributed step) the locally-essential tree of every peer: one
         // traversal per tree, so the stack never holds more than one tree's entries
         const uint64_t everyone = __ballot(valid);
-        for (int32_t t = -1; t < a.n_trees; ++t) {
+        const int32_t t_first = (a.part == 2) ? 0 : -1, t_end = (a.part == 1) ? 0 : a.n_trees;
+        for (int32_t t = t_first; t < t_end; ++t) {
             if (t >= 0 && t == a.self_rank) continue;
             int32_t base = (t < 0) ? 0 : (int32_t)(a.forest_base + (int64_t)t * a.let_cap);
             uint64_t mask = everyone;
@@ -365,7 +369,9 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
 
     float2 np = p;
     double2 np64{0.0, 0.0};
-    if (valid) {
+    if (a.part == 1) {
+        if (valid) a.acc_part[s] = float2{ax, ay};              // raw sums; part 2 carries on from here
+    } else if (valid) {
         const float gx = a.G * ax, gy = a.G * ay;
         const uint32_t body = a.perm[s];
         if (a.acc_out) a.acc_out[body] = float2{gx, gy};

@@ -207,10 +207,15 @@ class LetStepper:
     often) raises if a LET has outgrown its block since."""
 
     def __init__(self, engine, rank: int, world: int, let_cap: int, device: torch.device | None = None,
-                 ids=None):
-        """ids: global identifiers of this rank's bodies in upload order (kept through repartition())."""
+                 ids=None, overlap: bool = False):
+        """ids: global identifiers of this rank's bodies in upload order (kept through repartition()).
+        overlap: walk the local tree while the LETs are in flight (two walk launches instead of one).
+        The second launch costs 15-35 us per step on one MI355X (scripts/let_emulate.py: 0.280 -> 0.301
+        ms per rank at N = 1M on 8 ranks); whether the hidden all_to_all is worth more can only be
+        measured on a multi-GPU node, so it is off by default."""
         self.eng, self.rank, self.world, self.device = engine, rank, world, device
         self.ids = ids
+        self.overlap = overlap and hasattr(engine, "let_walk_local")
         self._configure(let_cap)
 
     def _configure(self, let_cap: int) -> None:
@@ -252,8 +257,16 @@ class LetStepper:
             out = torch.empty(self.recv.numel(), dtype=self.recv.dtype)
             dist.all_to_all_single(out, self.send.cpu())
             self.recv.copy_(out)
+        elif dist.is_initialized() and self.overlap:
+            # block q of send -> block rank of q's recv, on the collective's own stream; the local-tree
+            # walk does not need it, the second walk launch waits for it
+            work = dist.all_to_all_single(self.recv, self.send, async_op=True)
+            self.eng.let_walk_local()
+            work.wait()
+            self.eng.let_walk_remote(integrate)
+            return
         elif dist.is_initialized():
-            dist.all_to_all_single(self.recv, self.send)     # block q of send -> block rank of q's recv
+            dist.all_to_all_single(self.recv, self.send)
         if integrate:
             self.eng.let_walk()
         else:

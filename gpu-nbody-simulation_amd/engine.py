@@ -237,6 +237,12 @@ class BarnesHutEngine:
     def let_forces(self) -> None:
         self._check(self._lib.bh_let_forces(self._h))
 
+    def let_walk_local(self) -> None:
+        self._check(self._lib.bh_let_walk_local(self._h))
+
+    def let_walk_remote(self, integrate: bool = True) -> None:
+        self._check(self._lib.bh_let_walk_remote(self._h, 1 if integrate else 0))
+
     def let_counts(self, with_overflow: bool = False):
         """Quads packed for each peer in the last let_build (waits for the stream).  Raises BhError(-4)
         when a LET exceeded let_cap, unless with_overflow: then returns (counts, overflow flag)."""

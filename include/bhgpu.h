@@ -222,6 +222,12 @@ int bh_let_pointers(bh_ctx *ctx, void **lbounds, void **all_bounds, void **send,
 int bh_let_build(bh_ctx *ctx);
 int bh_let_walk(bh_ctx *ctx);
 int bh_let_forces(bh_ctx *ctx);
+/* bh_let_walk in two launches, so that the all_to_all can overlap the first: bh_let_walk_local walks
+ * the local tree only (needs bh_let_build, not the received blocks); bh_let_walk_remote adds the
+ * received LETs and finishes the step (integrate != 0) or only the forces.  Same sums in the same
+ * order as bh_let_walk when the launch runs one wavefront per 64 bodies. */
+int bh_let_walk_local(bh_ctx *ctx);
+int bh_let_walk_remote(bh_ctx *ctx, int32_t integrate);
 int bh_let_counts(bh_ctx *ctx, uint32_t *counts, int32_t *overflow);
 /* Run on an external HIP stream (e.g. torch's current stream), passed as void*. */
 int bh_set_stream(bh_ctx *ctx, void *hip_stream);

@@ -106,19 +106,27 @@ def main():
         for e in engs:
             e.let_build(); e.sync()
         exchange_lets()
-        let = []
+        let, let2 = [], []
         for e in engs:
-            for _ in range(3):
-                e.let_bounds(); e.let_build(); e.let_forces()
-            e.sync()
-            t0 = time.perf_counter()
-            for _ in range(a.reps):
-                e.let_bounds(); e.let_build(); e.let_forces()
-            e.sync()
-            let.append((time.perf_counter() - t0) / a.reps * 1e3)
+            for two, acc in ((False, let), (True, let2)):
+                def chain():
+                    e.let_bounds(); e.let_build()
+                    if two:
+                        e.let_walk_local(); e.let_walk_remote(False)
+                    else:
+                        e.let_forces()
+                for _ in range(3):
+                    chain()
+                e.sync()
+                t0 = time.perf_counter()
+                for _ in range(a.reps):
+                    chain()
+                e.sync()
+                acc.append((time.perf_counter() - t0) / a.reps * 1e3)
         for e in engs:
             e.close()
         row = {"world": world, "replicated_ms_max": max(rep), "let_ms_max": max(let), "let_ms_mean": float(np.mean(let)),
+               "let_two_launch_ms_max": max(let2), "let_two_launch_ms_mean": float(np.mean(let2)),
                "let_quads_mean": float(counts[counts > 0].mean()), "let_quads_max": int(counts.max()),
                "let_cap": cap, "all_to_all_bytes_per_rank": cap * 80 * (world - 1),
                "bodies_per_rank": cap_bodies}

@@ -38,7 +38,7 @@ class EmulatedRanks:
                               wrap_device(sd, world * nb, "|u1", dev), wrap_device(rv, world * nb, "|u1", dev), nb))
             self.engs.append(e)
 
-    def step(self, integrate=True):
+    def step(self, integrate=True, two_launches=False):
         for e in self.engs:
             e.let_bounds()
             e.sync()
@@ -56,7 +56,11 @@ class EmulatedRanks:
                     self.bufs[q][3][r * nb:(r + 1) * nb].copy_(self.bufs[r][2][q * nb:(q + 1) * nb])
         torch.cuda.synchronize()
         for e in self.engs:
-            e.let_walk() if integrate else e.let_forces()
+            if two_launches:
+                e.let_walk_local()
+                e.let_walk_remote(integrate)
+            else:
+                e.let_walk() if integrate else e.let_forces()
             e.sync()
 
     def gather(self, what):
@@ -173,3 +177,31 @@ def test_ranks_without_bodies():
     a = er.gather(lambda e: e.accelerations())
     er.close()
     assert rel(a, ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("no_split", [True, False])
+def test_two_launch_forest_walk_equals_the_single_launch(no_split):
+    """bh_let_walk_local + bh_let_walk_remote (what lets the all_to_all overlap the local walk) against
+    bh_let_walk: the same sums in the same order with one wavefront per group (bitwise), summation order
+    only with the level-synchronous walk."""
+    from gpu_nbody_simulation_amd.engine import FLAG_WALK_NO_SPLIT
+    n = 50000
+    m, p, v = IC.make("plummer", n, 12)
+    m = m * 1e-3
+    out = []
+    for two in (False, True):
+        er = EmulatedRanks(m, p, v, 3, let_cap=16384, max_depth=21, reference_compat=False,
+                           flags=FLAG_WALK_NO_SPLIT if no_split else 0)
+        er.step(integrate=False, two_launches=two)
+        a = er.gather(lambda e: e.accelerations())
+        er.step(two_launches=two)
+        er.step(two_launches=two)
+        out.append((a, er.gather(lambda e: e.download()[0]), er.gather(lambda e: e.download()[1])))
+        er.close()
+    (a1, p1, v1), (a2, p2, v2) = out
+    if no_split:
+        assert np.array_equal(a1, a2) and np.array_equal(p1, p2) and np.array_equal(v1, v2)
+    else:
+        r = rel(a2, a1)
+        assert np.median(r) < 5e-7 and np.quantile(r, 0.999) < 2e-5
+        assert np.abs(p2 - p1).max() < 1e-6
