@@ -10,8 +10,14 @@ reads that format (ours or the reference's files); `sweep` produces it with this
 `summarise` computes what the reference's plotters plot (median kernel/total time, speed-up and
 efficiency against the first row of each size); `plot` draws it when matplotlib is importable.
 
+`gpus` is the 1/2/4/8-GPU sweep the reference has no counterpart for: it runs the repository's bench.py
+once per GPU count (through torch.distributed.run for more than one), keeps the JSON lines, and prints
+speed-up, efficiency and the walk kernel's roofline fraction; `show-gpus` re-reads such a file.
+
     python -m gpu_nbody_simulation_amd.scaling sweep --bodies 65536 1048576 --simulations 10 --repeats 3
     python -m gpu_nbody_simulation_amd.scaling show scaling_results.txt
+    python -m gpu_nbody_simulation_amd.scaling gpus --gpus 1 2 4 8 --out gpu_scaling.jsonl -- --steps 20
+    python -m gpu_nbody_simulation_amd.scaling show-gpus gpu_scaling.jsonl --png gpu_scaling.png
 """
 from __future__ import annotations
 
@@ -105,6 +111,67 @@ def plot(rows, png_path):
     fig.savefig(png_path, dpi=120)
 
 
+def gpu_sweep(gpus, out_path, bench_args=(), runner=None, bench_path=None, port=29600):
+    """Run bench.py for every GPU count and append its JSON line to out_path.  runner(cmd) -> stdout
+    is injectable for tests; the default runs the command as a child process."""
+    import json
+    import os
+    import subprocess
+    bench_path = bench_path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    if runner is None:
+        def runner(cmd):
+            return subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+    rows = []
+    with open(out_path, "w") as f:
+        for k, g in enumerate(gpus):
+            cmd = [sys.executable]
+            if g > 1:
+                cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(g),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port + k)]
+            cmd += [bench_path, "--gpus", str(g), *bench_args]
+            line = [ln for ln in runner(cmd).splitlines() if ln.startswith("{")][-1]
+            rows.append(json.loads(line))
+            f.write(line + "\n")
+            f.flush()
+    return rows
+
+
+def summarise_gpus(rows):
+    """Speed-up and efficiency against the smallest GPU count of the file (strong scaling: same work;
+    weak: work grows with the GPU count, so efficiency = value / (gpus x value at the base))."""
+    rows = sorted(rows, key=lambda r: r["n_gpus"])
+    base = rows[0]
+    out = []
+    for r in rows:
+        ratio = r["n_gpus"] / base["n_gpus"]
+        sp = r["value"] / base["value"]
+        out.append({"n_gpus": r["n_gpus"], "value": r["value"], "ms_per_step": r["ms_per_step"], "speedup": sp,
+                    "efficiency": sp / ratio, "scaling": r.get("scaling", "strong"),
+                    "roofline_frac": (r.get("roofline") or {}).get("frac"),
+                    "workload": (r.get("config") or {}).get("workload")})
+    return out
+
+
+def plot_gpus(rows, png_path):
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    fig, ax = plt.subplots()
+    g = [r["n_gpus"] for r in rows]
+    ax.plot(g, [r["value"] for r in rows], marker="o", label="measured")
+    ax.plot(g, [rows[0]["value"] * x / g[0] for x in g], linestyle="--", color="gray", label="ideal")
+    ax.set_xscale("log", base=2)
+    ax.set_yscale("log")
+    ax.set_xticks(g)
+    ax.set_xticklabels([str(x) for x in g])
+    ax.set_xlabel("GPUs")
+    ax.set_ylabel("body-steps / s")
+    ax.set_title(rows[0].get("workload") or "")
+    ax.legend()
+    fig.savefig(png_path, dpi=120)
+    plt.close(fig)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -119,7 +186,30 @@ def main(argv=None):
     h = sub.add_parser("show")
     h.add_argument("file")
     h.add_argument("--png")
+    g = sub.add_parser("gpus")
+    g.add_argument("--gpus", type=int, nargs="+", default=[1, 2, 4, 8])
+    g.add_argument("--out", default="gpu_scaling.jsonl")
+    g.add_argument("--png")
+    g.add_argument("bench_args", nargs="*", help="passed to bench.py (put them after --)")
+    hg = sub.add_parser("show-gpus")
+    hg.add_argument("file")
+    hg.add_argument("--png")
     a = ap.parse_args(argv)
+    if a.cmd in ("gpus", "show-gpus"):
+        import json
+        if a.cmd == "gpus":
+            raw = gpu_sweep(a.gpus, a.out, a.bench_args)
+        else:
+            raw = [json.loads(ln) for ln in open(a.file) if ln.startswith("{")]
+        rows = summarise_gpus(raw)
+        print("%6s %16s %12s %9s %11s %14s" % ("gpus", "body-steps/s", "ms/step", "speed-up", "efficiency", "roofline frac"))
+        for r in rows:
+            print("%6d %16.4e %12.4f %9.2f %11.2f %14s" % (r["n_gpus"], r["value"], r["ms_per_step"], r["speedup"],
+                                                            r["efficiency"],
+                                                            "-" if r["roofline_frac"] is None else "%.3f" % r["roofline_frac"]))
+        if a.png:
+            plot_gpus(rows, a.png)
+        return 0
     if a.cmd == "sweep":
         sweep(a.bodies, a.threads, a.simulations, a.repeats, a.out,
               ["--init", "gpu", "--precision", a.precision, "--max-depth", str(a.max_depth)])

@@ -94,6 +94,41 @@ def save_positions(path: str, frames) -> None:
                 f.write("%f %d %f %f \n" % (t, i, x, y))
 
 
+def parse_positions_file(path: str):
+    """(times[T], positions[T, n, 2]) from a positions_*.txt trajectory (`t i x y ` per line, what
+    save_positions / savePositions write and plot_2d.py:7-16 reads).  Frames must be complete."""
+    rows = np.loadtxt(path, ndmin=2)
+    if rows.size == 0:
+        return np.zeros(0), np.zeros((0, 0, 2))
+    body = rows[:, 1].astype(np.int64)
+    n = int(body.max()) + 1
+    if len(rows) % n or not np.array_equal(body, np.tile(np.arange(n), len(rows) // n)):
+        raise ValueError(f"{path}: not a sequence of complete frames of {n} bodies")
+    return rows[::n, 0].copy(), rows[:, 2:4].reshape(-1, n, 2).copy()
+
+
+def plot_trajectories(path: str, png_path: str, max_bodies: int = 64) -> int:
+    """Counterpart of the reference's plot_2d.py: one polyline per body (the first max_bodies of them),
+    written to png_path.  Returns the number of bodies drawn."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    _, pos = parse_positions_file(path)
+    nb = min(pos.shape[1], max_bodies)
+    fig, ax = plt.subplots(figsize=(8, 8))
+    for b in range(nb):
+        ax.plot(pos[:, b, 0], pos[:, b, 1], marker="o", markersize=2, linewidth=0.8)
+    ax.set_title("N-Body Problem Visualization")
+    ax.set_xlabel("X Coordinate")
+    ax.set_ylabel("Y Coordinate")
+    ax.axhline(0, color="gray", linestyle="--", linewidth=0.5)
+    ax.axvline(0, color="gray", linestyle="--", linewidth=0.5)
+    ax.grid(True)
+    fig.savefig(png_path, dpi=100)
+    plt.close(fig)
+    return nb
+
+
 _OCC = re.compile(r"occupantIndex=(-?\d+)\s+occupantPos=\(([-0-9.e+]+),([-0-9.e+]+)\)")
 
 

@@ -4,6 +4,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NVCC = os.path.join(ROOT, "gpu-nbody-simulation_amd", "compat", "nvcc")
 
@@ -51,3 +53,32 @@ def test_project_argument_parsing():
     assert mac == {"N_BODIES": 40000, "N_THREADS": 32, "N_SIMULATIONS": 10}        # project.cu:1-11
     a, mac = project._parse([])
     assert mac == {"N_BODIES": 40000, "N_THREADS": 1024, "N_SIMULATIONS": 10}
+
+
+def test_gpu_sweep_collects_bench_lines_and_computes_efficiency(tmp_path):
+    """scaling.gpu_sweep / summarise_gpus (GPUs on the x axis): the command line it
+    builds per GPU count is the driver's, the JSON lines are kept verbatim, efficiency follows `scaling`."""
+    import json
+    from gpu_nbody_simulation_amd import scaling
+    seen = []
+
+    def runner(cmd):
+        seen.append(cmd)
+        g = int(cmd[cmd.index("--gpus") + 1])
+        line = {"metric": "body-steps/sec", "value": 1.0e9 * g ** 0.5, "n_gpus": g, "ms_per_step": 1.0 / g ** 0.5,
+                "scaling": "strong", "roofline": {"frac": 0.1} if g == 1 else None, "config": {"workload": "w"}}
+        return "noise\n" + json.dumps(line) + "\n"
+
+    out = tmp_path / "g.jsonl"
+    rows = scaling.gpu_sweep([1, 4], str(out), ["--steps", "5"], runner=runner, bench_path="bench.py")
+    assert [r["n_gpus"] for r in rows] == [1, 4]
+    assert "torch.distributed.run" not in seen[0] and seen[0][-4:] == ["--gpus", "1", "--steps", "5"]
+    assert seen[1][1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node" in seen[1]
+    assert seen[1][seen[1].index("--master-addr") + 1] == "127.0.0.1"
+    summary = scaling.summarise_gpus([json.loads(l) for l in open(out)])
+    assert summary[1]["speedup"] == pytest.approx(2.0) and summary[1]["efficiency"] == pytest.approx(0.5)
+    assert summary[0]["roofline_frac"] == 0.1 and summary[1]["roofline_frac"] is None
+    png = tmp_path / "g.png"
+    scaling.plot_gpus(summary, str(png))
+    assert png.stat().st_size > 1000
+    assert scaling.main(["show-gpus", str(out)]) == 0

@@ -89,3 +89,24 @@ def test_parser_on_the_reference_output(gold, tmp_path):
     occ = [x[6][0][0] for x in e if x[6]]
     assert len(occ) <= 1793 and sum(1 for o in occ if o == -1) == 773 and sum(1 for o in occ if o >= 0) == 996
     assert sum(1 for x in e if not x[6]) >= 1292
+
+
+def test_positions_file_round_trip_and_plot(tmp_path):
+    """savePositions format (project.cu:855-863) written, read back, and drawn (our plot_2d.py)."""
+    from gpu_nbody_simulation_amd import textio
+    rng = np.random.default_rng(0)
+    frames = [(float(t), rng.uniform(-1, 1, (5, 2))) for t in range(4)]
+    path = tmp_path / "positions.txt"
+    textio.save_positions(str(path), frames)
+    first = open(path).readline()
+    assert first.count(" ") == 4 and first.endswith(" \n")            # "t i x y " with the trailing blank
+    t, pos = textio.parse_positions_file(str(path))
+    assert np.array_equal(t, np.arange(4.0)) and pos.shape == (4, 5, 2)
+    np.testing.assert_allclose(pos, np.stack([f[1] for f in frames]), atol=5e-7)   # "%f": 6 decimals
+    png = tmp_path / "plot_2d.png"
+    assert textio.plot_trajectories(str(path), str(png), max_bodies=3) == 3
+    assert png.stat().st_size > 1000
+    with open(path, "a") as f:
+        f.write("4.000000 0 0.000000 0.000000 \n")                    # an incomplete frame
+    with pytest.raises(ValueError):
+        textio.parse_positions_file(str(path))
