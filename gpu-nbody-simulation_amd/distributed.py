@@ -299,6 +299,17 @@ class LetStepper:
                                "results since the last check are invalid -- autotune() again")
         return mx
 
+    def run(self, nsteps: int, check_every: int = 50, grow_at: float = 0.8) -> None:
+        """nsteps steps with the block size looked after: every check_every steps the largest LET is
+        compared with let_cap (one synchronisation); above grow_at x let_cap the blocks are re-sized
+        BEFORE anything overflows, and an overflow that happened anyway raises (see check())."""
+        for s in range(nsteps):
+            self.step()
+            if (s + 1) % check_every == 0 or s + 1 == nsteps:
+                mx = self.check()
+                if mx > grow_at * self.let_cap:
+                    self._configure((int(1.5 * mx / grow_at) + 255) // 256 * 256)
+
     def repartition(self, partition=partition_orb) -> int:
         """Re-deal the bodies to the ranks (bodies drift; a rank's bodies spread, its boxes overlap its
         neighbours' and the LETs grow).  Set-up-grade: the state goes through the host and the object

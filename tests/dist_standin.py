@@ -145,7 +145,13 @@ class LetStandInEngine:
             blk[:12] = np.array([self.rank, q, cnt], dtype=np.int32).view(np.uint8)
             blk[12:12 + 12 * cnt] = rec[:3 * cnt].view(np.uint8)
 
+    counts_override = None
+    overflow_override = None
+
     def let_counts(self, with_overflow=False):
+        if self.counts_override is not None or self.overflow_override is not None:
+            c = [self.counts_override or 0] * self.world
+            return (c, bool(self.overflow_override)) if with_overflow else c
         if with_overflow:
             return list(self.counts), self.overflow
         if self.overflow:

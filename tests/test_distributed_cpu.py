@@ -117,6 +117,7 @@ def _let_worker(rank, world, port, n, steps, out_dir):
             st.repartition(lambda pp, w: partition_hilbert(pp, w, align=16)[::-1])
             cap = st.let_cap
     largest = st.check()
+    st.run(0)
     pos, vel = eng.download()
     mine = st.ids
     np.savez(os.path.join(out_dir, f"let{rank}.npz"), pos=pos, vel=vel, idx=mine, cap=cap, largest=largest,
@@ -214,3 +215,18 @@ def test_partition_orb_snaps_the_cut_of_a_symmetric_input_to_the_grid_line():
     assert p[lo][:, ax].max() < 0 <= p[hi][:, ax].min()      # no body on the wrong side of the midline
     lo2, hi2 = partition_orb(p, 2, snap=False)
     assert abs(len(lo2) - len(hi2)) <= 1
+
+
+def test_let_stepper_run_grows_the_blocks_before_they_overflow():
+    from dist_standin import LetStandInEngine
+    from gpu_nbody_simulation_amd.distributed import LetStepper
+    m, p, v = _inputs(200)
+    eng = LetStandInEngine()
+    eng.upload(p, v, m)
+    st = LetStepper(eng, 0, 1, let_cap=64, device=torch.device("cpu"))
+    eng.counts_override = 60                                  # pretend the LETs have grown to 60 of 64 quads
+    st.run(3, check_every=2)
+    assert st.let_cap >= 112 and st.let_cap % 256 == 0        # re-sized to 1.5 x 60 / 0.8, rounded up
+    eng.overflow_override = True
+    with pytest.raises(RuntimeError):
+        st.run(1)
