@@ -46,6 +46,7 @@ struct bh_ctx {
     int sort_passes = 0;
     bool state64 = false;          // fp64 state arrays: exact and mixed precision
     int walk_mode = 0; bool walk_xcd = false; int walk_split = 0;   // 0 = automatic
+    bool sort_wave_rank = true;    // radix_scatter_w (wave-private ranking); BH_SORT_WAVE_RANK=0: radix_scatter
     int build_items = 0;           // 0 = automatic, else keys per thread in the sort / scan kernels (2, 4, 8)
     bool hilbert = false;                // fp32 mode: Hilbert-ordered keys (BH_HILBERT=0 disables, A/B)  // BH_WALK_PIPE / BH_WALK_XCD override (A/B)
     int partial_count = 0;         // > 0: partial[] holds per-workgroup min/max of the current positions
@@ -213,9 +214,14 @@ int enqueue_build_t(bh_ctx *c)
                                c->keys[cur], c->radix_counts, n, shift, (int)nbl);
             hipLaunchKernelGGL(radix_rowscan, dim3(kRadix), dim3(kBlock), 0, st, c->radix_counts, c->bsum_sort,
                                (int)nbl);
-            hipLaunchKernelGGL((radix_scatter<ITEMS == kItems ? kSortItems : ITEMS>), dim3(nbl), dim3(kBlock), 0, st,
-                               c->keys[cur], c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1], c->radix_counts,
-                               c->bsum_sort, n, shift, (int)nbl);
+            if (c->sort_wave_rank)
+                hipLaunchKernelGGL((radix_scatter_w<ITEMS == kItems ? kSortItems : ITEMS>), dim3(nbl), dim3(kBlock), 0,
+                                   st, c->keys[cur], c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1],
+                                   c->radix_counts, c->bsum_sort, n, shift, (int)nbl);
+            else
+                hipLaunchKernelGGL((radix_scatter<ITEMS == kItems ? kSortItems : ITEMS>), dim3(nbl), dim3(kBlock), 0,
+                                   st, c->keys[cur], c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1],
+                                   c->radix_counts, c->bsum_sort, n, shift, (int)nbl);
             cur ^= 1;
         }
         c->keys_sorted = c->keys[cur];
@@ -401,6 +407,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     if (const char *e = std::getenv("BH_WALK_XCD")) c->walk_xcd = std::atoi(e) != 0;
     if (const char *e = std::getenv("BH_WALK_SPLIT")) c->walk_split = std::atoi(e);
     if (const char *e = std::getenv("BH_BUILD_ITEMS")) c->build_items = std::atoi(e);
+    if (const char *e = std::getenv("BH_SORT_WAVE_RANK")) c->sort_wave_rank = std::atoi(e) != 0;
     if (const char *e = std::getenv("BH_SORT_ONESWEEP")) c->sort_onesweep = std::atoi(e) != 0;
     c->hilbert = !c->exact;
     if (const char *e = std::getenv("BH_HILBERT")) c->hilbert = !c->exact && std::atoi(e) != 0;

@@ -178,6 +178,103 @@ __global__ __launch_bounds__(kBlock) void radix_scatter(const uint64_t *__restri
     }
 }
 
+// ---- scatter with wave-private ranking --------------------------------------------------------------
+// radix_scatter above synchronises the workgroup three times per round of 256 keys (24 barriers per
+// 2,048-key tile), and a workgroup's rounds are sequential: with every tile resident at once the
+// kernel's time IS that chain.  Here wave w owns the contiguous keys [w * 64 * ITEMS, (w+1) * 64 * ITEMS)
+// of the tile: (1) every wave counts its digits into its own LDS histogram, (2) one barrier, the
+// histograms are turned into per-wave start offsets (digit base + tile prefix + earlier waves),
+// (3) one barrier, then each wave ranks and scatters its rounds on its own -- the only shared state
+// left is the wave's own offset row, and LDS operations of one wave are ordered.  Element order is
+// (wave, round, lane) = tile order, and ranks within a round follow lane order, so the sort stays
+// stable and its output is bitwise the same.
+template <int ITEMS>
+__global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__restrict__ kin,
+                                                           const uint32_t *__restrict__ vin,
+                                                           uint64_t *__restrict__ kout,
+                                                           uint32_t *__restrict__ vout,
+                                                           const uint32_t *__restrict__ offs,
+                                                           const uint32_t *__restrict__ row_total, int64_t n,
+                                                           int shift, int nblocks)
+{
+    // (4) the tile is first sorted by digit INTO LDS, then written out in that order: the ~8 keys a
+    // digit has in a 2,048-key tile leave as one contiguous run instead of 8 separate partial-line
+    // writes from 8 different rounds
+    constexpr int TILE = kBlock * ITEMS;
+    __shared__ uint32_t woff[kWavesPerBlock][kRadix];       // counts, then running local offsets, per wave
+    __shared__ int32_t gdelta[kRadix];                      // global position - position in the sorted tile
+    __shared__ uint64_t skey[TILE];
+    __shared__ uint32_t sval[TILE];
+    __shared__ uint32_t sm[kWavesPerBlock + 1];
+    const int t = threadIdx.x, w = wave_id(), l = lane_id();
+#pragma unroll
+    for (int k = 0; k < kWavesPerBlock; ++k) woff[k][t] = 0;
+    __syncthreads();
+
+    const int64_t tile_base = (int64_t)blockIdx.x * TILE;
+    const int64_t base = tile_base + (int64_t)w * (kWave * ITEMS);
+    uint64_t key[ITEMS];
+    uint32_t val[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int64_t i = base + r * kWave + l;
+        const bool valid = i < n;
+        key[r] = valid ? kin[i] : ~0ull;
+        val[r] = valid ? vin[i] : 0u;
+        if (valid) atomicAdd(&woff[w][(uint32_t)(key[r] >> shift) & (kRadix - 1)], 1u);
+    }
+    __syncthreads();
+    {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int k = 0; k < kWavesPerBlock; ++k) cnt += woff[k][t];
+        uint32_t all;
+        const uint32_t digit_base = block_exclusive_sum(row_total[t], sm, all);
+        const uint32_t lstart = block_exclusive_sum(cnt, sm, all);           // digit t's run in the sorted tile
+        gdelta[t] = (int32_t)(digit_base + offs[(int64_t)t * nblocks + blockIdx.x]) - (int32_t)lstart;
+        uint32_t run = lstart;
+#pragma unroll
+        for (int k = 0; k < kWavesPerBlock; ++k) { const uint32_t c = woff[k][t]; woff[k][t] = run; run += c; }
+    }
+    __syncthreads();
+
+    const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int64_t i = base + r * kWave + l;
+        const bool valid = i < n;
+        const uint32_t d = (uint32_t)(key[r] >> shift) & (kRadix - 1);
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < kRadixBits; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const uint32_t rank = __popcll(peers & lt);
+        uint32_t o = 0;
+        if (valid) o = woff[w][d];                          // every peer reads the same word ...
+        if (valid) {
+            skey[o + rank] = key[r];
+            sval[o + rank] = val[r];
+        }
+        if (valid && rank == 0) woff[w][d] = o + (uint32_t)__popcll(peers);   // ... before its leader advances it
+    }
+    __syncthreads();
+    const int64_t left = n - tile_base;
+    const int count = (left < TILE) ? (int)left : TILE;
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int lp = r * kBlock + t;
+        if (lp < count) {
+            const uint64_t k = skey[lp];
+            const int64_t dst = (int64_t)lp + gdelta[(uint32_t)(k >> shift) & (kRadix - 1)];
+            kout[dst] = k;
+            vout[dst] = sval[lp];
+        }
+    }
+}
+
 // =================================================================================================
 // Single-kernel-per-pass variant ("onesweep": chained scan with decoupled look-back, Adinets &
 // Merrill 2022), 2 + P launches instead of 3P.  MEASURED AND NOT THE DEFAULT (BH_SORT_ONESWEEP=1
