@@ -51,8 +51,16 @@ struct bh_ctx {
     bool hilbert = false;                // fp32 mode: Hilbert-ordered keys (BH_HILBERT=0 disables, A/B)  // BH_WALK_PIPE / BH_WALK_XCD override (A/B)
     int partial_count = 0;         // > 0: partial[] holds per-workgroup min/max of the current positions
 
-    // caller-order state (double2/double or float2/float)
+    // state (double2/double or float2/float).  Exact mode: caller order.  fp32 / mixed: DEVICE order --
+    // every reorder_every-th build the bodies are physically permuted into that build's sorted order
+    // (the gathers through `perm` in prep and in the walk's epilogue then touch neighbouring lines),
+    // and orig[slot] remembers the caller's index; every host-facing call translates back.
     void *pos = nullptr, *vel = nullptr, *mass = nullptr, *force = nullptr;
+    void *pos2 = nullptr, *vel2 = nullptr, *mass2 = nullptr, *force2 = nullptr;
+    uint32_t *orig = nullptr, *orig2 = nullptr;
+    bool orig_identity = true;
+    int reorder_every = 16;        // BH_REORDER_EVERY; 0 = never
+    int64_t builds = 0;            // builds since the last upload
     // sorted-order copies (fp32 mode)
     float2 *spos = nullptr, *spos_out = nullptr, *svel = nullptr;
     float *smass = nullptr;
@@ -158,6 +166,24 @@ constexpr int64_t kSmallBuildBodies = 327680;    // up to here: tiles of 512 ins
 constexpr int64_t kMediumBuildBodies = 786432;   // up to here: tiles of 1,024
 constexpr int kSmallItems = 2;
 
+// Physically permute the state into the sorted order of the build that has just produced `perm`
+// (sorted index -> slot); afterwards slot == sorted index, so perm becomes the identity.
+template <typename Real2, typename Real>
+__global__ __launch_bounds__(kBlock) void reorder_state_kernel(uint32_t *__restrict__ perm, const Real2 *__restrict__ pos,
+                                                                const Real2 *__restrict__ vel, const Real *__restrict__ mass,
+                                                                const float2 *__restrict__ acc, const uint32_t *__restrict__ orig,
+                                                                Real2 *__restrict__ pos2, Real2 *__restrict__ vel2,
+                                                                Real *__restrict__ mass2, float2 *__restrict__ acc2,
+                                                                uint32_t *__restrict__ orig2, int64_t n)
+{
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t b = perm[s];
+    pos2[s] = pos[b]; vel2[s] = vel[b]; mass2[s] = mass[b]; acc2[s] = acc[b];
+    orig2[s] = orig ? orig[b] : b;                            // orig == nullptr: slots still are caller indices
+    perm[s] = (uint32_t)s;
+}
+
 template <bool EXACT, bool STATE64 = EXACT, int ITEMS = kItems>
 int enqueue_build_t(bh_ctx *c)
 {
@@ -168,7 +194,7 @@ int enqueue_build_t(bh_ctx *c)
     const int64_t n = c->n;
     const int Dm = c->Dm;
     hipStream_t st = c->stream;
-    const Real2 *pos = static_cast<const Real2 *>(c->pos);
+    const Real2 *pos = static_cast<const Real2 *>(c->pos);     // (re-read after a reorder)
     const Real *mass = static_cast<const Real *>(c->mass);
 
     // 1. root box (ComputeRootBounds, project.cu:536-573); the per-workgroup partials usually
@@ -226,6 +252,21 @@ int enqueue_build_t(bh_ctx *c)
         }
         c->keys_sorted = c->keys[cur];
         c->perm = c->vals[cur];
+        if constexpr (!EXACT) {
+            if (c->reorder_every > 0 && c->builds % c->reorder_every == 0) {
+                hipLaunchKernelGGL((reorder_state_kernel<Real2, Real>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st,
+                                   c->perm, pos, static_cast<const Real2 *>(c->vel), mass,
+                                   static_cast<const float2 *>(c->force), c->orig_identity ? nullptr : c->orig,
+                                   static_cast<Real2 *>(c->pos2), static_cast<Real2 *>(c->vel2),
+                                   static_cast<Real *>(c->mass2), static_cast<float2 *>(c->force2), c->orig2, n);
+                std::swap(c->pos, c->pos2); std::swap(c->vel, c->vel2); std::swap(c->mass, c->mass2);
+                std::swap(c->force, c->force2); std::swap(c->orig, c->orig2);
+                c->orig_identity = false;
+                pos = static_cast<const Real2 *>(c->pos);
+                mass = static_cast<const Real *>(c->mass);
+            }
+        }
+        c->builds += 1;
 
         // 4. cells owned by each sorted neighbour pair (+ fp32: sorted copies and prefix-sum terms),
         // 5. their ranks / the prefix sums
@@ -370,6 +411,7 @@ int check_overflow(bh_ctx *c)
 
 // ================================================================================================
 static int download_pairs(bh_ctx *c, const void *dev, double *host, int64_t count, bool is64);
+static int to_caller_order(bh_ctx *c, double *host, int per);
 
 extern "C" {
 
@@ -408,6 +450,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     if (const char *e = std::getenv("BH_WALK_SPLIT")) c->walk_split = std::atoi(e);
     if (const char *e = std::getenv("BH_BUILD_ITEMS")) c->build_items = std::atoi(e);
     if (const char *e = std::getenv("BH_SORT_WAVE_RANK")) c->sort_wave_rank = std::atoi(e) != 0;
+    if (const char *e = std::getenv("BH_REORDER_EVERY")) c->reorder_every = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("BH_SORT_ONESWEEP")) c->sort_onesweep = std::atoi(e) != 0;
     c->hilbert = !c->exact;
     if (const char *e = std::getenv("BH_HILBERT")) c->hilbert = !c->exact && std::atoi(e) != 0;
@@ -436,6 +479,13 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     { char *t; A(&t, cap * 2 * rs); c->vel = t; }
     { char *t; A(&t, cap * rs); c->mass = t; }
     { char *t; A(&t, cap * 2 * (c->exact ? sizeof(double) : sizeof(float))); c->force = t; }
+    if (!c->exact) {
+        { char *t; A(&t, cap * 2 * rs); c->pos2 = t; }
+        { char *t; A(&t, cap * 2 * rs); c->vel2 = t; }
+        { char *t; A(&t, cap * rs); c->mass2 = t; }
+        { char *t; A(&t, cap * 2 * sizeof(float)); c->force2 = t; }
+        A(&c->orig, cap); A(&c->orig2, cap);
+    }
     A(&c->keys[0], cap); A(&c->keys[1], cap); A(&c->vals[0], cap); A(&c->vals[1], cap);
     A(&c->cnt, cap + 1);
     { const size_t nbl = std::max<size_t>(blocks_for(cap, kSortTile), blocks_for(std::min<int64_t>(cap, 1 << 22), kBlock * kSmallItems));
@@ -515,6 +565,8 @@ int bh_upload(bh_ctx *c, const double *pos, const double *vel, const double *mas
     c->uploaded = true;
     c->tree_valid = false;
     c->steps_done = 0;
+    c->orig_identity = true;
+    c->builds = 0;
     return BH_OK;
 }
 
@@ -527,6 +579,19 @@ static int download_pairs(bh_ctx *c, const void *dev, double *host, int64_t coun
         BH_HIP(c, hipMemcpy(t.data(), dev, count * sizeof(float), hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < count; ++i) host[i] = (double)t[i];
     }
+    return BH_OK;
+}
+
+// host array with `per` doubles per body, read from the device in DEVICE order -> caller order
+static int to_caller_order(bh_ctx *c, double *host, int per)
+{
+    if (c->exact || c->orig_identity || c->n == 0) return BH_OK;
+    const int64_t n = c->n;
+    std::vector<uint32_t> o(n);
+    BH_HIP(c, hipMemcpy(o.data(), c->orig, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<double> t(host, host + (size_t)per * n);
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < per; ++k) host[(size_t)per * o[i] + k] = t[(size_t)per * i + k];
     return BH_OK;
 }
 
@@ -556,6 +621,8 @@ int bh_initialize(bh_ctx *c, int64_t n, uint64_t seed, int32_t kind, double lowe
     c->uploaded = true;
     c->tree_valid = false;
     c->steps_done = 0;
+    c->orig_identity = true;
+    c->builds = 0;
     return BH_OK;
 }
 
@@ -565,7 +632,8 @@ int bh_download_masses(bh_ctx *c, double *mass)
     if (!c->uploaded) return fail(c, BH_ERR_STATE, "bh_download_masses before bh_upload/bh_initialize");
     BH_HIP(c, hipSetDevice(c->device));
     BH_HIP(c, hipStreamSynchronize(c->stream));
-    return download_pairs(c, c->mass, mass, c->n, c->state64);
+    int rc = download_pairs(c, c->mass, mass, c->n, c->state64);
+    return rc ? rc : to_caller_order(c, mass, 1);
 }
 
 int bh_sync(bh_ctx *c)
@@ -588,8 +656,12 @@ int bh_download(bh_ctx *c, double *pos, double *vel)
     if (rc) return rc;
     BH_HIP(c, hipStreamSynchronize(c->stream));
     rc = download_pairs(c, c->pos, pos, 2 * c->n, c->state64);
+    if (!rc) rc = to_caller_order(c, pos, 2);
     if (rc) return rc;
-    if (vel) rc = download_pairs(c, c->vel, vel, 2 * c->n, c->state64);
+    if (vel) {
+        rc = download_pairs(c, c->vel, vel, 2 * c->n, c->state64);
+        if (!rc) rc = to_caller_order(c, vel, 2);
+    }
     return rc;
 }
 
@@ -659,7 +731,7 @@ int bh_get_forces(bh_ctx *c, double *out)
         if (rc) return rc;
         for (int64_t i = 0; i < c->n; ++i) { out[2 * i] *= m[i]; out[2 * i + 1] *= m[i]; }
     }
-    return BH_OK;
+    return to_caller_order(c, out, 2);
 }
 
 int bh_get_accel(bh_ctx *c, double *out)
@@ -674,7 +746,7 @@ int bh_get_accel(bh_ctx *c, double *out)
         BH_HIP(c, hipMemcpy(m.data(), c->mass, c->n * sizeof(double), hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < c->n; ++i) { out[2 * i] /= m[i]; out[2 * i + 1] /= m[i]; }
     }
-    return BH_OK;
+    return to_caller_order(c, out, 2);
 }
 
 // ---- tree export: DFS pre-order, children in index order (TraverseTreeToFile, project.cu:504-534)
@@ -695,6 +767,11 @@ static int export_tree_host(bh_ctx *c, std::vector<bh_tree_node> &out, std::vect
     std::vector<NodeAux> aux;
     std::vector<uint32_t> perm(std::max<int64_t>(c->n, 1));
     if (c->n > 0) BH_HIP(c, hipMemcpy(perm.data(), c->perm, c->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (!c->exact && !c->orig_identity && c->n > 0) {          // slots -> the caller's body indices
+        std::vector<uint32_t> o(c->n);
+        BH_HIP(c, hipMemcpy(o.data(), c->orig, c->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (auto &b : perm) b = o[b];
+    }
     if (c->exact) {
         gd.resize(nn); ld.resize(nn);
         BH_HIP(c, hipMemcpy(gd.data(), c->gd, nn * sizeof(NodeD), hipMemcpyDeviceToHost));
@@ -778,6 +855,7 @@ int bh_write_quadtree_file(bh_ctx *c, const char *path)
     if (rc) return rc;
     std::vector<double> pos(std::max<int64_t>(2 * c->n, 2));
     rc = download_pairs(c, c->pos, pos.data(), 2 * c->n, c->state64);
+    if (!rc) rc = to_caller_order(c, pos.data(), 2);
     if (rc) return rc;
     FILE *fp = std::fopen(path, "w");
     if (!fp) return fail(c, BH_ERR_IO, std::string("cannot open ") + path);

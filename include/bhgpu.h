@@ -183,8 +183,12 @@ int bh_stats(bh_ctx *ctx, bh_stats_t *out);
  * The reference is single-GPU.  One process per GPU owns a contiguous range [lo, hi) of
  * the Morton-sorted bodies: bh_step then walks and integrates only that range, and the
  * host exchanges the updated ranges (torch.distributed all_gather over RCCL) through the
- * device pointers below.  Pointers stay valid until bh_destroy; element types follow the
- * context's precision (double2/double or float2/float). */
+ * device pointers below.  The exchange buffers stay valid until bh_destroy; element types follow
+ * the context's precision (double2/double or float2/float).  bh_device_state exposes the state
+ * arrays as the device holds them: in exact mode that is the caller's order; in fp32 / mixed mode
+ * the engine re-orders the bodies into sorted order every 16th tree build (so that its gathers
+ * stay local) and swaps buffers when it does -- ask again after stepping, and use bh_download for
+ * the caller's order. */
 int bh_set_owned_fraction(bh_ctx *ctx, int32_t rank, int32_t world);
 int bh_device_state(bh_ctx *ctx, void **pos, void **vel, void **mass, int64_t *n,
                     int32_t *elem_bytes);

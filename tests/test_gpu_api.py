@@ -84,3 +84,41 @@ def test_reupload_smaller_and_reuse_context():
         e.upload(p[:100], v[:100], m[:100]); e.step(2)
         e.upload(p, v, m); e.step(2); b = e.download()
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("precision", [G.Precision.F32, G.Precision.MIXED])
+def test_periodic_reordering_of_the_state_is_invisible_to_the_caller(monkeypatch, precision):
+    """fp32 / mixed contexts physically re-order the bodies into sorted order every 16th build
+    (BH_REORDER_EVERY); everything host-facing must keep speaking the caller's order: positions,
+    velocities, masses, accelerations, the occupant indices of the exported tree."""
+    from gpu_nbody_simulation_amd import initial_conditions as IC
+    n = 30011
+    m, p, v = IC.make("plummer", n, 4)
+    m = m * np.linspace(1e-4, 2e-4, n)                        # distinct masses: a permutation would show
+    res = {}
+    for every in ("0", "16", "1"):
+        monkeypatch.setenv("BH_REORDER_EVERY", every)
+        with G.BarnesHutEngine(G.BhConfig(capacity=n, precision=precision, max_depth=18, reference_compat=False)) as e:
+            e.upload(p, v, m)
+            e.step(35)                                        # re-ordered at builds 0, 16, 32 (every = 16)
+            pos, vel = e.download()
+            e.compute_forces()
+            acc = e.accelerations()
+            frc = e.forces()
+            mass = e.masses()
+            nodes, depth = e.export_tree()
+        res[every] = (pos, vel, acc, mass, nodes)
+        expect_m = m if precision == G.Precision.MIXED else m.astype(np.float32).astype(np.float64)
+        assert np.array_equal(mass, expect_m)
+        np.testing.assert_allclose(frc, acc * mass[:, None], rtol=1e-12)
+        # a single-occupant leaf names a body whose (caller-order) position lies inside the leaf's box
+        leaf = nodes[nodes["particle"] >= 0]
+        idx = leaf["particle"].astype(np.int64)
+        assert len(np.unique(idx)) == len(idx) > n // 2
+        q = pos[idx]
+        assert ((q[:, 0] >= leaf["xmin"]) & (q[:, 0] <= leaf["xmax"]) & (q[:, 1] >= leaf["ymin"]) & (q[:, 1] <= leaf["ymax"])).all()
+    for every in ("16", "1"):
+        for a, b in zip(res["0"][:3], res[every][:3]):
+            # same bodies, same forces; only the order of a few fp32 sums (equal-key ties) may differ
+            np.testing.assert_allclose(b, a, rtol=2e-4, atol=1e-12)
+        assert np.median(np.abs(res[every][0] - res["0"][0])) == 0.0
