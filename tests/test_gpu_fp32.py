@@ -277,3 +277,42 @@ def test_split_walk_equals_the_one_wave_walk(monkeypatch, split, kind, n, md):
         np.testing.assert_allclose([root["xmin"], root["xmax"], root["ymin"], root["ymax"]],
                                    [pos[:, 0].min() - 0.1 * ex, pos[:, 0].max() + 0.1 * ex,
                                     pos[:, 1].min() - 0.1 * ex, pos[:, 1].max() + 0.1 * ex], rtol=1e-6)
+
+
+@pytest.mark.parametrize("precision", [G.Precision.F32, G.Precision.MIXED])
+def test_ragged_and_tiny_sizes(precision):
+    """n = 0, 1, 2, ... around the wave (64), workgroup (256) and tile (512) boundaries: every launch
+    shape of the fp32 pipeline (empty grids, one partial tile, the level-synchronous walk with fewer
+    bodies than a wave) against the oracle, through two steps so that the re-ordered state, the walk's
+    bounds partials and the integrator are exercised as well."""
+    rng = np.random.default_rng(17)
+    for n in (0, 1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1000):
+        p = f32(rng.uniform(-0.1, 0.1, (n, 2)))
+        v = f32(rng.uniform(-1e-4, 1e-4, (n, 2)))
+        m = f32(10.0 ** rng.uniform(-5, -3, n))
+        with engine(max(n, 1), precision=precision, max_depth=21, reference_compat=False, flags=FLAG_WALK_STATS) as e:
+            e.upload(p, v, m)
+            e.compute_forces()
+            a = e.accelerations()
+            st = e.stats()
+            e.step(2)
+            p2, v2 = e.download()
+        assert a.shape == (n, 2) and p2.shape == (n, 2)
+        if n == 0:
+            continue
+        if n == 1:
+            assert np.array_equal(a, np.zeros((1, 2)))
+            np.testing.assert_allclose(p2, p + 2 * v, rtol=1e-6)
+            continue
+        t = O.build_tree(p, m, 0)
+        f, ws = O.compute_forces(t, p, m, compat_self_skip=False, with_stats=True)
+        ref = f / m[:, None]
+        assert st.n_bodies == n and abs(st.interactions - ws.interactions) <= max(2, 1e-3 * ws.interactions)
+        r = rel_err(a, ref)
+        assert np.median(r) < 1e-5 and r.max() < 5e-3, (n, np.median(r), r.max())
+        # two steps of the oracle (uncapped tree, per-body MAC, fp64)
+        pos, vel = p.copy(), v.copy()
+        for _ in range(2):
+            tt = O.build_tree(pos, m, 0)
+            _, vel, pos = O.integrate(O.compute_forces(tt, pos, m, compat_self_skip=False), m, vel, pos)
+        np.testing.assert_allclose(p2, pos, rtol=0, atol=2e-6 * 0.2)
