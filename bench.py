@@ -214,6 +214,15 @@ def main():
             se.upload(pf, vf, mass)
             se.compute_forces()
             ss = se.stats()
+            if use_let:
+                # sanity of the distributed forces: rank 0's accelerations of the last step against a
+                # single tree over the gathered state (partial cells differ at the 1e-3 level; a broken
+                # exchange would differ at O(1))
+                a_one, a_let = se.accelerations()[mine], eng.accelerations()
+                nrm = np.linalg.norm(a_one, axis=1)
+                ok = nrm > 0
+                let_info["accel_median_rel_diff_vs_single_tree"] = float(
+                    np.median(np.linalg.norm(a_let - a_one, axis=1)[ok] / nrm[ok])) if ok.any() else 0.0
         u64 = ss.wave_nodes / n                      # distinct nodes per body per 64-body group
         # algorithmic bytes of ONE walk+integrate launch (DESIGN.md "Roofline"):
         #   per body: sorted pos 8 + perm 4 + vel r/w 16 + pos w 8 + accel w 8 = 44 B

@@ -76,7 +76,8 @@ SIGNATURES = {
     "bh_device_sorted": (C.c_int, [_ctx, C.POINTER(_vp), C.POINTER(_vp)]),
     "bh_scatter_sorted": (C.c_int, [_ctx]),
     "bh_set_stream": (C.c_int, [_ctx, _vp]),
-    "bh_let_configure": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int64]),
+    "bh_let_local_quads": (C.c_int, [_ctx, C.POINTER(C.c_int64)]),
+    "bh_let_configure": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int64, C.c_int64]),
     "bh_let_bounds": (C.c_int, [_ctx]),
     "bh_let_pointers": (C.c_int, [_ctx, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                                   C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),

@@ -90,6 +90,7 @@ struct bh_ctx {
     // distributed step with locally-essential trees (bh_let_*): this context holds only its own bodies
     bool let_mode = false, external_box = false;
     int64_t let_cap = 0, quads_local = 0;
+    int64_t forest_base = 0;       // first quad of the received blocks: THE SAME ON EVERY RANK (>= quads_local)
     uint64_t *needmask = nullptr;
     uint32_t *let_tsum = nullptr, *let_outidx = nullptr;
     QuadF *let_send = nullptr;
@@ -374,7 +375,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         a.integrate = integrate ? 1 : 0; a.to_sorted = to_sorted ? 1 : 0;
         a.n_trees = c->let_mode ? c->world : 0; a.self_rank = c->let_mode ? c->rank : -1;
         a.part = part; a.acc_part = c->acc_part;
-        a.forest_base = c->quads_local; a.let_cap = c->let_cap;
+        a.forest_base = c->forest_base; a.let_cap = c->let_cap;
         // the register-lane stack holds 64 entries; the walk never needs more than 3*Dm + 2
         const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0 || (3 * c->Dm + 2 > kWave);
         const int mode = c->let_mode ? 0 : c->walk_mode;
@@ -992,10 +993,22 @@ int bh_scatter_sorted(bh_ctx *c)
 }
 
 // ---- distributed step with locally-essential trees --------------------------------------------------
-int bh_let_configure(bh_ctx *c, int32_t rank, int32_t world, int64_t let_cap)
+int bh_let_local_quads(bh_ctx *c, int64_t *local_quads)
+{
+    if (!c || !local_quads) return fail(c, BH_ERR_ARG, "bh_let_local_quads: null argument");
+    *local_quads = c->internal_cap + 1;
+    return BH_OK;
+}
+
+int bh_let_configure(bh_ctx *c, int32_t rank, int32_t world, int64_t let_cap, int64_t forest_base)
 {
     if (!c || world < 1 || world > kMaxWorld || rank < 0 || rank >= world || let_cap < 1)
         return fail(c, BH_ERR_ARG, "bh_let_configure: bad rank/world/let_cap (world <= 64)");
+    if (forest_base < c->internal_cap + 1)
+        return fail(c, BH_ERR_ARG, "bh_let_configure: forest_base must be the LARGEST bh_let_local_quads of all ranks "
+                                   "(a sender writes child links in the receiver's index space)");
+    if (forest_base + (int64_t)world * let_cap > 0x7fffffffLL)
+        return fail(c, BH_ERR_ARG, "bh_let_configure: forest too large for 32-bit quad indices");
     if (c->exact) return fail(c, BH_ERR_STATE, "bh_let_configure: fp32 and mixed precision only");
     BH_HIP(c, hipSetDevice(c->device));
     BH_HIP(c, hipStreamSynchronize(c->stream));
@@ -1003,8 +1016,8 @@ int bh_let_configure(bh_ctx *c, int32_t rank, int32_t world, int64_t let_cap)
     auto A = [&](auto **pp, size_t count) { if (!rc) rc = dev_alloc(c, pp, count); };
     if (c->let_mode) {
         // a second call may only change let_cap (LetStepper.autotune: size the blocks from measured counts)
-        if (rank != c->rank || world != c->world)
-            return fail(c, BH_ERR_STATE, "bh_let_configure: rank/world cannot change once configured");
+        if (rank != c->rank || world != c->world || forest_base != c->forest_base)
+            return fail(c, BH_ERR_STATE, "bh_let_configure: rank/world/forest_base cannot change once configured");
         if (let_cap == c->let_cap) return BH_OK;
         dev_free(c, c->qf); dev_free(c, c->let_send);
         c->qf = nullptr; c->let_send = nullptr;
@@ -1022,7 +1035,8 @@ int bh_let_configure(bh_ctx *c, int32_t rank, int32_t world, int64_t let_cap)
         A(&c->let_ctr, 1);
     }
     c->let_cap = let_cap;
-    A(&c->qf, (size_t)(c->quads_local + (int64_t)world * let_cap));
+    c->forest_base = forest_base;
+    A(&c->qf, (size_t)(forest_base + (int64_t)world * let_cap));
     A(&c->let_send, (size_t)world * let_cap);
     if (rc) return rc;
     BH_HIP(c, hipMemset(c->let_ctr, 0, sizeof(LetCounters)));
@@ -1061,7 +1075,7 @@ int bh_let_pointers(bh_ctx *c, void **lbounds, void **all_bounds, void **send, v
     if (lbounds) *lbounds = c->lbounds;
     if (all_bounds) *all_bounds = c->all_bounds;
     if (send) *send = c->let_send;
-    if (recv) *recv = c->qf + c->quads_local;
+    if (recv) *recv = c->qf + c->forest_base;
     if (block_bytes) *block_bytes = c->let_cap * (int64_t)sizeof(QuadF);
     if (boxes_per_rank) *boxes_per_rank = kLetBoxes;
     return BH_OK;
@@ -1089,7 +1103,7 @@ int bh_let_build(bh_ctx *c)
                        c->internal_cap, c->let_tsum, ntiles, c->let_outidx, nq);
     hipLaunchKernelGGL(let_pack_kernel, dim3(blocks_for(nq, kBlock)), dim3(kBlock), 0, st, c->qf, c->needmask,
                        c->let_outidx, nq, c->world, c->rank, c->ctr, c->internal_cap, c->let_send,
-                       (uint32_t)c->let_cap, c->quads_local + (int64_t)c->rank * c->let_cap);
+                       (uint32_t)c->let_cap, c->forest_base + (int64_t)c->rank * c->let_cap);
     BH_HIP(c, hipGetLastError());
     return BH_OK;
 }

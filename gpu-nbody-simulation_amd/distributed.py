@@ -216,11 +216,19 @@ class LetStepper:
         self.eng, self.rank, self.world, self.device = engine, rank, world, device
         self.ids = ids
         self.overlap = overlap and hasattr(engine, "let_walk_local")
+        # the received blocks must start at the same quad index on every rank (a sender writes links in
+        # the receiver's index space) although the ranks' capacities differ: agree on the largest
+        fb = torch.tensor([engine.let_local_quads()], dtype=torch.int64)
+        if dist.is_initialized() and world > 1:
+            if dist.get_backend() != "gloo":
+                fb = fb.to(device)
+            dist.all_reduce(fb, op=dist.ReduceOp.MAX)
+        self.forest_base = int(fb.item())
         self._configure(let_cap)
 
     def _configure(self, let_cap: int) -> None:
         self.let_cap = let_cap
-        self.eng.let_configure(self.rank, self.world, let_cap)
+        self.eng.let_configure(self.rank, self.world, let_cap, self.forest_base)
         lb, ab, sd, rv, nb, k = self.eng.let_pointers()
         if isinstance(lb, torch.Tensor):        # stand-in engines hand tensors over directly
             self.lbounds, self.all_bounds, self.send, self.recv = lb, ab, sd, rv

@@ -212,8 +212,19 @@ class BarnesHutEngine:
         return p.value, v.value, m.value, n.value, eb.value
 
     # -- distributed step with locally-essential trees ----------------------------------------
-    def let_configure(self, rank: int, world: int, let_cap: int) -> None:
-        self._check(self._lib.bh_let_configure(self._h, rank, world, let_cap))
+    def let_local_quads(self) -> int:
+        """Quads this context reserves for its own tree; the forest_base of let_configure must be the
+        maximum of this over all ranks."""
+        q = C.c_int64()
+        self._check(self._lib.bh_let_local_quads(self._h, C.byref(q)))
+        return q.value
+
+    def let_configure(self, rank: int, world: int, let_cap: int, forest_base: int | None = None) -> None:
+        """forest_base None: this context's own let_local_quads() -- only right when every rank's
+        context has the same capacity."""
+        if forest_base is None:
+            forest_base = self.let_local_quads()
+        self._check(self._lib.bh_let_configure(self._h, rank, world, let_cap, forest_base))
         self._let_world = world
 
     def let_bounds(self) -> None:

@@ -219,7 +219,11 @@ int bh_scatter_sorted(bh_ctx *ctx);
  * check the counts before trusting a run.  bh_let_configure may be called again with the same
  * rank/world and a new let_cap (size the blocks from measured counts).  bh_let_forces =
  * bh_let_walk without the integration.  fp32 and mixed precision. */
-int bh_let_configure(bh_ctx *ctx, int32_t rank, int32_t world, int64_t let_cap);
+/* forest_base: where the received blocks start in a context's quad array.  A sender writes the child
+ * links of a LET in the RECEIVER's index space, so this must be ONE number on all ranks: the largest
+ * bh_let_local_quads of any rank (all_reduce MAX it once; contexts of equal capacity agree anyway). */
+int bh_let_local_quads(bh_ctx *ctx, int64_t *local_quads);
+int bh_let_configure(bh_ctx *ctx, int32_t rank, int32_t world, int64_t let_cap, int64_t forest_base);
 int bh_let_bounds(bh_ctx *ctx);
 int bh_let_pointers(bh_ctx *ctx, void **lbounds, void **all_bounds, void **send, void **recv,
                     int64_t *block_bytes, int32_t *boxes_per_rank);

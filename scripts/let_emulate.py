@@ -67,6 +67,7 @@ def main():
                  else partition_orb(p, world, snap=a.partition == "orb"))
         cap_bodies = max(len(ix) for ix in parts)
         engs, bufs = [], []
+        fb = None
 
         def wire(e):
             lb, ab, sd, rv, nb, k = e.let_pointers()
@@ -74,10 +75,13 @@ def main():
                     wrap_device(sd, world * nb, "|u1", dev), wrap_device(rv, world * nb, "|u1", dev), nb)
 
         for r, ix in enumerate(parts):
-            e = G.BarnesHutEngine(G.BhConfig(capacity=cap_bodies, **cfg))
+            e = G.BarnesHutEngine(G.BhConfig(capacity=max(len(ix), 1), **cfg))     # sized for its own bodies
             e.upload(p[ix], v[ix], m[ix])
-            e.let_configure(r, world, 1 << 16)
-            engs.append(e); bufs.append(wire(e))
+            engs.append(e)
+        fb = max(e.let_local_quads() for e in engs)                               # the agreed forest_base
+        for r, e in enumerate(engs):
+            e.let_configure(r, world, 1 << 16, fb)
+            bufs.append(wire(e))
 
         def exchange_bounds():
             for e in engs:
@@ -101,7 +105,7 @@ def main():
         counts = np.array([e.let_counts() for e in engs])
         cap = max(256, (int(1.5 * counts.max()) + 255) // 256 * 256)
         for i, e in enumerate(engs):
-            e.let_configure(i, world, cap); bufs[i] = wire(e)
+            e.let_configure(i, world, cap, fb); bufs[i] = wire(e)
         exchange_bounds()
         for e in engs:
             e.let_build(); e.sync()

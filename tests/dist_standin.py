@@ -109,7 +109,14 @@ class LetStandInEngine:
     def masses(self):
         return self.mass.astype(np.float64)
 
-    def let_configure(self, rank, world, let_cap):
+    def let_local_quads(self):
+        if not hasattr(self, "_lq"):
+            self._lq = 2 * self.n + 256                       # fixed by the first upload ("capacity"); differs between ranks
+        return self._lq
+
+    def let_configure(self, rank, world, let_cap, forest_base):
+        assert forest_base >= self.let_local_quads()
+        self.forest_base_seen = forest_base
         self.rank, self.world, self.let_cap = rank, world, let_cap
         nb = let_cap * self.QUAD_BYTES
         self.lbounds = torch.zeros(4 * self.BOXES, dtype=torch.float64)

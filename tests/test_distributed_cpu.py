@@ -121,6 +121,7 @@ def _let_worker(rank, world, port, n, steps, out_dir):
     pos, vel = eng.download()
     mine = st.ids
     np.savez(os.path.join(out_dir, f"let{rank}.npz"), pos=pos, vel=vel, idx=mine, cap=cap, largest=largest,
+             forest_base=eng.forest_base_seen, local_quads=eng.let_local_quads(),
              overflowed=overflowed, bounds=eng.seen_bounds)
     dist.barrier()
     dist.destroy_process_group()
@@ -155,6 +156,9 @@ def test_let_stepper_ranks_reproduce_the_direct_sum(tmp_path, world, n):
         if r:
             assert np.array_equal(b, first_bounds)
         first_bounds = b
+    # all ranks configured the same forest_base: the largest local-quad count of any rank
+    fbs = [int(np.load(tmp_path / f"let{r}.npz")["forest_base"]) for r in range(world)]
+    assert len(set(fbs)) == 1 and fbs[0] >= max(int(np.load(tmp_path / f"let{r}.npz")["local_quads"]) for r in range(world))
     assert (seen == 1).all()                               # the partition covers every body once
     assert len(caps) == 1                                  # all ranks agreed on the new block size
     np.testing.assert_allclose(got_v, vel.astype(np.float64), rtol=2e-5, atol=1e-9)

@@ -27,16 +27,19 @@ class EmulatedRanks:
         self.parts = partition(pos, world)
         dev = torch.device("cuda", 0)
         self.engs, self.bufs = [], []
-        cap = max(len(ix) for ix in self.parts)
-        for r, ix in enumerate(self.parts):
-            cfg.setdefault("precision", G.Precision.F32)
-            e = G.BarnesHutEngine(G.BhConfig(capacity=cap, **cfg))
+        cfg.setdefault("precision", G.Precision.F32)
+        # every context sized for ITS OWN bodies, as bench.py does: the contexts' quad arrays then differ
+        # in size, and only the agreed forest_base makes a sender's links land in the receiver's blocks
+        for ix in self.parts:
+            e = G.BarnesHutEngine(G.BhConfig(capacity=max(len(ix), 1), **cfg))
             e.upload(pos[ix], vel[ix], mass[ix])
-            e.let_configure(r, world, let_cap)
+            self.engs.append(e)
+        self.forest_base = max(e.let_local_quads() for e in self.engs)
+        for r, e in enumerate(self.engs):
+            e.let_configure(r, world, let_cap, self.forest_base)
             lb, ab, sd, rv, nb, k = e.let_pointers()
             self.bufs.append((wrap_device(lb, 4 * k, "<f8", dev), wrap_device(ab, 4 * k * world, "<f8", dev),
                               wrap_device(sd, world * nb, "|u1", dev), wrap_device(rv, world * nb, "|u1", dev), nb))
-            self.engs.append(e)
 
     def step(self, integrate=True, two_launches=False):
         for e in self.engs:
@@ -205,3 +208,30 @@ def test_two_launch_forest_walk_equals_the_single_launch(no_split):
         r = rel(a2, a1)
         assert np.median(r) < 5e-7 and np.quantile(r, 0.999) < 2e-5
         assert np.abs(p2 - p1).max() < 1e-6
+
+
+def test_contexts_of_different_capacity_need_the_agreed_forest_base():
+    """The layout bug this guards against: a sender used its OWN local-quad count as the start of the
+    receiver's blocks, which is only right when all contexts have the same capacity."""
+    n = 20000
+    m, p, v = IC.make("plummer", n, 3)
+    er = EmulatedRanks(m, p, v, 3, let_cap=16384, partition=lambda pp, w: [np.arange(0, 3000), np.arange(3000, 12000), np.arange(12000, n)],
+                       max_depth=21, reference_compat=False)
+    assert len({e.let_local_quads() for e in er.engs}) == 3          # three different array sizes
+    er.step(integrate=False)
+    a = er.gather(lambda e: e.accelerations())
+    for e in er.engs:
+        e.let_counts()                                                # (raises if a LET did not fit)
+    with pytest.raises(G.BhError):                                    # a smaller base than the largest context's is refused
+        small = min(e.let_local_quads() for e in er.engs)
+        big = max(er.engs, key=lambda e: e.let_local_quads())
+        big.let_configure(er.engs.index(big), 3, 16384, small)
+    er.close()
+    ref = O.direct_forces(p, m) / m[:, None]
+    with G.BarnesHutEngine(G.BhConfig(capacity=n, precision=G.Precision.F32, max_depth=21, reference_compat=False)) as e:
+        e.upload(p, v, m)
+        e.compute_forces()
+        r1 = rel(e.accelerations(), ref)
+    r = rel(a, ref)
+    # the Barnes-Hut error of a single tree at theta 0.5 (monopoles), not garbage
+    assert np.median(r) <= 1.2 * np.median(r1) and np.quantile(r, 0.99) <= 1.5 * np.quantile(r1, 0.99)
