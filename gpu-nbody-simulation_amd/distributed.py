@@ -187,7 +187,13 @@ class ShardedStepper:
             # fixed-size block per rank; the send block is a copy so the collective never aliases
             # its own output (2 MB per rank at N = 1M on 8 ranks)
             mine = buf[self.rank * c2:(self.rank + 1) * c2].clone()
-            if dist.is_initialized():
+            if dist.is_initialized() and buf.is_cuda and dist.get_backend() == "gloo":
+                # rehearsal only (several ranks sharing one GPU, where RCCL cannot run): through the host
+                self.eng.sync()
+                out = torch.empty(self.world * c2, dtype=buf.dtype)
+                dist.all_gather_into_tensor(out, mine.cpu())
+                buf[: self.world * c2].copy_(out)
+            elif dist.is_initialized():
                 dist.all_gather_into_tensor(buf[: self.world * c2], mine)
             else:
                 assert self.world == 1

@@ -117,3 +117,16 @@ def test_bench_let_path_with_three_ranks_sharing_the_gpu(tmp_path):
     # the state gathered from the three ranks after 4 steps is the state one GPU reaches
     assert abs(d["n_nodes"] - one["n_nodes"]) <= 0.001 * one["n_nodes"]
     assert abs(d["interactions_per_body"] - one["interactions_per_body"]) <= 1e-3 * one["interactions_per_body"]
+    # the replicated decomposition through the same rehearsal path (the box allows 6 processes on the
+    # GPU, this test process included, so world sizes stay at 3-4)
+    for extra, world, port in ((["--decomposition", "replicated"], 3, 29537), ([], 4, 29538)):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(port)] + base + ["--gpus", str(world), "--backend", "gloo"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["n_gpus"] == world
+        assert abs(d["n_nodes"] - one["n_nodes"]) <= 0.001 * one["n_nodes"]
+        assert abs(d["interactions_per_body"] - one["interactions_per_body"]) <= 1e-3 * one["interactions_per_body"]
+        if not extra:
+            assert d["let"]["accel_median_rel_diff_vs_single_tree"] < 5e-3
