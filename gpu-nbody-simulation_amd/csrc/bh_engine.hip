@@ -271,22 +271,30 @@ int enqueue_build_t(bh_ctx *c)
 
         // 4. cells owned by each sorted neighbour pair (+ fp32: sorted copies and prefix-sum terms),
         // 5. their ranks / the prefix sums
-        const unsigned nbs = blocks_for(n + 1, TILE);
         using SReal2 = typename std::conditional<EXACT, double2, float2>::type;    // what the walk reads
         using SReal = typename std::conditional<EXACT, double, float>::type;
-        hipLaunchKernelGGL((prep_kernel<EXACT, ITEMS, Real2, Real, SReal2, SReal>), dim3(nbs), dim3(kBlock), 0, st,
-                           c->keys_sorted, c->perm, pos, mass, c->cnt, c->bsum_u32, (SReal2 *)c->spos,
-                           (SReal *)c->smass, c->terms, c->bsum_d3, c->coarse, n, Dm);
-        if (nbs <= 4u * kBlock) {
-            // few tiles: every workgroup sums the tile totals before it itself (no scan_top2 launch)
-            hipLaunchKernelGGL((scan_apply2<EXACT, ITEMS, true>), dim3(nbs), dim3(kBlock), 0, st, c->cnt, c->bsum_u32,
-                               c->terms, c->bsum_d3, (int)nbs, n, c->cell_first, c->internal_cap, c->ctr);
-        } else {
-            hipLaunchKernelGGL(scan_top2, dim3(EXACT ? 1 : 2), dim3(kBlock), 0, st, c->bsum_u32, c->bsum_d3, (int)nbs,
-                               c->ctr);
-            hipLaunchKernelGGL((scan_apply2<EXACT, ITEMS, false>), dim3(nbs), dim3(kBlock), 0, st, c->cnt, c->bsum_u32,
-                               c->terms, c->bsum_d3, (int)nbs, n, c->cell_first, c->internal_cap, c->ctr);
-        }
+        // elements per thread in prep / scan_apply2: the sort's tile size, except that between 768k and
+        // 2M bodies tiles of 1,024 are still the better choice for these two (a workgroup's rows are a
+        // chain of load -> scan -> store; measured at N = 1M: 42.5 -> 33 us for the pair)
+        auto scan_part = [&](auto si_tag) {
+            constexpr int SI = decltype(si_tag)::value;
+            const unsigned nbs = blocks_for(n + 1, kBlock * SI);
+            hipLaunchKernelGGL((prep_kernel<EXACT, SI, Real2, Real, SReal2, SReal>), dim3(nbs), dim3(kBlock), 0, st,
+                               c->keys_sorted, c->perm, pos, mass, c->cnt, c->bsum_u32, (SReal2 *)c->spos,
+                               (SReal *)c->smass, c->terms, c->bsum_d3, c->coarse, n, Dm);
+            if (nbs <= 8u * kBlock) {
+                // few tiles: every workgroup sums the tile totals before it itself (no scan_top2 launch)
+                hipLaunchKernelGGL((scan_apply2<EXACT, SI, true>), dim3(nbs), dim3(kBlock), 0, st, c->cnt, c->bsum_u32,
+                                   c->terms, c->bsum_d3, (int)nbs, n, c->cell_first, c->internal_cap, c->ctr);
+            } else {
+                hipLaunchKernelGGL(scan_top2, dim3(EXACT ? 1 : 2), dim3(kBlock), 0, st, c->bsum_u32, c->bsum_d3,
+                                   (int)nbs, c->ctr);
+                hipLaunchKernelGGL((scan_apply2<EXACT, SI, false>), dim3(nbs), dim3(kBlock), 0, st, c->cnt, c->bsum_u32,
+                                   c->terms, c->bsum_d3, (int)nbs, n, c->cell_first, c->internal_cap, c->ctr);
+            }
+        };
+        if (ITEMS == kItems && n <= (int64_t)1 << 21) scan_part(std::integral_constant<int, 4>{});
+        else scan_part(std::integral_constant<int, ITEMS>{});
     } else {
         c->keys_sorted = c->keys[0];
         c->perm = c->vals[0];

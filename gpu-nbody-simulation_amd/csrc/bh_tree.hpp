@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void scan_top2(uint32_t *__restrict__ bsum_
 
 // per tile: cnt -> exclusive offsets (ranks), fp32: terms -> exclusive prefix sums (n+1 entries);
 // row by row (256 consecutive elements per block scan), so accesses are coalesced.
-// FOLD: bsum_* hold the raw tile TOTALS written by prep_kernel (at most 4 * kBlock of them) and every
+// FOLD: bsum_* hold the raw tile TOTALS written by prep_kernel (at most 8 * kBlock of them) and every
 // workgroup sums the tiles before it itself -- one launch less for launches of few bodies, where
 // scan_top2 is nothing but its ~5 us of launch; workgroup 0 publishes the cell count.
 template <bool EXACT, int ITEMS, bool FOLD>
