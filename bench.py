@@ -55,8 +55,11 @@ def parse():
                     help="multi-GPU scheme (DESIGN.md 9): 'let' = ORB partition, local trees, locally-"
                          "essential-tree exchange (bodies live on one rank only); 'replicated' = every rank "
                          "builds the whole tree and walks a share, one all_gather per step")
-    ap.add_argument("--let-overlap", action="store_true",
-                    help="LET decomposition: walk the local tree while the all_to_all is in flight")
+    ap.add_argument("--let-overlap", choices=["auto", "on", "off"], default="auto",
+                    help="LET decomposition: walk the local tree while the all_to_all is in flight (two walk "
+                         "launches instead of one).  auto: from 4 ranks up, where the all_to_all (3+ peers) is "
+                         "expected to cost more than the 15-20 us of the second launch; unmeasured on this "
+                         "1-GPU development box")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearsal only (collectives staged through the host; lets several ranks "
                          "share one GPU together with BHGPU_REHEARSE_ON_DEVICE)")
@@ -158,7 +161,8 @@ def main():
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
     if use_let:
         eng.upload(pos[mine], vel[mine], mass[mine])  # this rank's bodies, resident in HBM from here on
-        stepper = LetStepper(eng, rank, world, let_cap=1 << 14, device=dev, overlap=a.let_overlap)
+        overlap = a.let_overlap == "on" or (a.let_overlap == "auto" and world >= 4 and a.backend == "nccl")
+        stepper = LetStepper(eng, rank, world, let_cap=1 << 14, device=dev, overlap=overlap)
         cap = stepper.autotune()                      # block size from the measured LET sizes (untimed)
     else:
         eng.upload(pos, vel, mass)                    # bodies resident in HBM from here on
@@ -256,7 +260,7 @@ def main():
             "config": {"workload": f"{a.init}_N{n}_theta{a.theta}", "n_bodies": n, "theta": a.theta,
                        "max_depth": a.max_depth, "init": a.init, "seed": a.seed,
                        "parallelism": "1 GPU" if not sharded else
-                       (f"orb x{world}, local trees + LET all_to_all/step" + (" (overlapped)" if a.let_overlap else "") if use_let
+                       (f"orb x{world}, local trees + LET all_to_all/step" + (" (overlapped)" if overlap else "") if use_let
                         else f"replicated build, hilbert-range walk x{world}, all_gather/step")},
             "minteractions_per_s": ss.interactions * a.steps / elapsed / 1e6,
             "interactions_per_body": ss.interactions / n,

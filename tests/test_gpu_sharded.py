@@ -74,7 +74,7 @@ def test_bench_exchange_path_on_real_rccl_single_rank(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for port, decomposition, extra in ((29533, "replicated", []), (29534, "let", []), (29536, "let", ["--let-overlap"])):
+    for port, decomposition, extra in ((29533, "replicated", []), (29534, "let", []), (29536, "let", ["--let-overlap", "on"])):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1",
                "--steps", "3", "--warmup", "1", "--n-bodies", "65536", "--max-depth", "16", "--force-sharded",
