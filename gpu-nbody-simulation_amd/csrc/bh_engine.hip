@@ -235,20 +235,30 @@ int enqueue_build_t(bh_ctx *c)
                 cur ^= 1;
             }
         } else
+        if (c->sort_wave_rank) {
+            // default: kSortBits-wide digits, wave-private ranking, digit-sorted write-out
+            constexpr int SB = kSortBits, SR = 1 << SB, SI = (ITEMS == kItems ? kSortItems : ITEMS);
+            const int passes = (2 * Dm + SB - 1) / SB;
+            for (int p = 0; p < passes; ++p) {
+                const int shift = p * SB;
+                hipLaunchKernelGGL((radix_hist<SI, SB>), dim3(nbl), dim3(kBlock), 0, st, c->keys[cur], c->radix_counts, n,
+                                   shift, (int)nbl);
+                hipLaunchKernelGGL(radix_rowscan, dim3(SR), dim3(kBlock), 0, st, c->radix_counts, c->bsum_sort, (int)nbl);
+                hipLaunchKernelGGL((radix_scatter_w<SI, SB>), dim3(nbl), dim3(kBlock), 0, st, c->keys[cur], c->vals[cur],
+                                   c->keys[cur ^ 1], c->vals[cur ^ 1], c->radix_counts, c->bsum_sort, n, shift,
+                                   (int)nbl);
+                cur ^= 1;
+            }
+        } else
         for (int p = 0; p < c->sort_passes; ++p) {
             const int shift = p * kRadixBits;
             hipLaunchKernelGGL((radix_hist<ITEMS == kItems ? kSortItems : ITEMS>), dim3(nbl), dim3(kBlock), 0, st,
                                c->keys[cur], c->radix_counts, n, shift, (int)nbl);
             hipLaunchKernelGGL(radix_rowscan, dim3(kRadix), dim3(kBlock), 0, st, c->radix_counts, c->bsum_sort,
                                (int)nbl);
-            if (c->sort_wave_rank)
-                hipLaunchKernelGGL((radix_scatter_w<ITEMS == kItems ? kSortItems : ITEMS>), dim3(nbl), dim3(kBlock), 0,
-                                   st, c->keys[cur], c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1],
-                                   c->radix_counts, c->bsum_sort, n, shift, (int)nbl);
-            else
-                hipLaunchKernelGGL((radix_scatter<ITEMS == kItems ? kSortItems : ITEMS>), dim3(nbl), dim3(kBlock), 0,
-                                   st, c->keys[cur], c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1],
-                                   c->radix_counts, c->bsum_sort, n, shift, (int)nbl);
+            hipLaunchKernelGGL((radix_scatter<ITEMS == kItems ? kSortItems : ITEMS>), dim3(nbl), dim3(kBlock), 0, st,
+                               c->keys[cur], c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1], c->radix_counts,
+                               c->bsum_sort, n, shift, (int)nbl);
             cur ^= 1;
         }
         c->keys_sorted = c->keys[cur];
@@ -498,8 +508,8 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     A(&c->keys[0], cap); A(&c->keys[1], cap); A(&c->vals[0], cap); A(&c->vals[1], cap);
     A(&c->cnt, cap + 1);
     { const size_t nbl = std::max<size_t>(blocks_for(cap, kSortTile), blocks_for(std::min<int64_t>(cap, 1 << 22), kBlock * kSmallItems));
-      A(&c->radix_counts, (size_t)kRadix * nbl);
-      A(&c->bsum_sort, kRadix + 8);
+      A(&c->radix_counts, (size_t)(1 << kSortBits) * nbl);
+      A(&c->bsum_sort, (1 << kSortBits) + 8);
       c->os_status_words = (int64_t)kMaxPasses * nbl * kRadix;
       A(&c->os_status, c->os_status_words); A(&c->os_ghist, kMaxPasses * kRadix); A(&c->os_counter, kMaxPasses);
       A(&c->os_err, 4); }

@@ -99,24 +99,31 @@ __global__ __launch_bounds__(kBlock) void radix_rowscan(uint32_t *__restrict__ c
 constexpr int kRadix = 1 << kRadixBits;
 static_assert(kRadix == kBlock, "one thread per digit");
 
+// Digit width of the default sort.  10 bits (the 40-bit keys of max_depth 21 in 4 passes instead of 5)
+// was measured and lost at every size: build 0.241 vs 0.215 ms at N = 1M, 0.093 vs 0.090 at 65k, 3.29 vs
+// 2.80 at 16.7M -- with 1,024 digits a 2,048-key tile has two keys per digit, so the digit-sorted
+// write-out degenerates into 16-byte runs and the count matrix is four times larger.
+constexpr int kSortBits = 8;
 // ITEMS keys per thread: 8 (tiles of 2,048) when there are enough tiles to fill the GPU, 2 (tiles of
-// 512) for launches of few bodies, where a workgroup's 8 sequential rounds are pure latency
-template <int ITEMS>
+// 512) for launches of few bodies, where a workgroup's 8 sequential rounds are pure latency.
+// BITS: digit width; counts[digit * nblocks + block].
+template <int ITEMS, int BITS = kRadixBits>
 __global__ __launch_bounds__(kBlock) void radix_hist(const uint64_t *__restrict__ keys,
                                                       uint32_t *__restrict__ counts, int64_t n,
                                                       int shift, int nblocks)
 {
-    __shared__ uint32_t h[kRadix];
-    h[threadIdx.x] = 0;
+    constexpr int R = 1 << BITS;
+    __shared__ uint32_t h[R];
+    for (int d = threadIdx.x; d < R; d += kBlock) h[d] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * (kBlock * ITEMS);
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = base + r * kBlock + threadIdx.x;
-        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (kRadix - 1)], 1u);
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (R - 1)], 1u);
     }
     __syncthreads();
-    counts[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    for (int d = threadIdx.x; d < R; d += kBlock) counts[(int64_t)d * nblocks + blockIdx.x] = h[d];
 }
 
 template <int ITEMS>
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter(const uint64_t *__restri
 // left is the wave's own offset row, and LDS operations of one wave are ordered.  Element order is
 // (wave, round, lane) = tile order, and ranks within a round follow lane order, so the sort stays
 // stable and its output is bitwise the same.
-template <int ITEMS>
+template <int ITEMS, int BITS = kRadixBits>
 __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__restrict__ kin,
                                                            const uint32_t *__restrict__ vin,
                                                            uint64_t *__restrict__ kout,
@@ -197,18 +204,21 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
                                                            const uint32_t *__restrict__ row_total, int64_t n,
                                                            int shift, int nblocks)
 {
-    // (4) the tile is first sorted by digit INTO LDS, then written out in that order: the ~8 keys a
-    // digit has in a 2,048-key tile leave as one contiguous run instead of 8 separate partial-line
-    // writes from 8 different rounds
+    // (4) the tile is first sorted by digit INTO LDS, then written out in that order: the keys a digit
+    // has in a tile leave as one contiguous run instead of separate partial-line writes from
+    // different rounds
     constexpr int TILE = kBlock * ITEMS;
-    __shared__ uint32_t woff[kWavesPerBlock][kRadix];       // counts, then running local offsets, per wave
-    __shared__ int32_t gdelta[kRadix];                      // global position - position in the sorted tile
+    constexpr int R = 1 << BITS, DPT = R / kBlock;          // digits per thread (thread t owns DPT*t ..)
+    static_assert(R % kBlock == 0, "whole digits per thread");
+    __shared__ uint32_t woff[kWavesPerBlock][R];            // counts, then running local offsets, per wave
+    __shared__ int32_t gdelta[R];                           // global position - position in the sorted tile
     __shared__ uint64_t skey[TILE];
     __shared__ uint32_t sval[TILE];
     __shared__ uint32_t sm[kWavesPerBlock + 1];
     const int t = threadIdx.x, w = wave_id(), l = lane_id();
+    for (int d = t; d < R; d += kBlock)
 #pragma unroll
-    for (int k = 0; k < kWavesPerBlock; ++k) woff[k][t] = 0;
+        for (int k = 0; k < kWavesPerBlock; ++k) woff[k][d] = 0;
     __syncthreads();
 
     const int64_t tile_base = (int64_t)blockIdx.x * TILE;
@@ -221,20 +231,34 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
         const bool valid = i < n;
         key[r] = valid ? kin[i] : ~0ull;
         val[r] = valid ? vin[i] : 0u;
-        if (valid) atomicAdd(&woff[w][(uint32_t)(key[r] >> shift) & (kRadix - 1)], 1u);
+        if (valid) atomicAdd(&woff[w][(uint32_t)(key[r] >> shift) & (R - 1)], 1u);
     }
     __syncthreads();
     {
-        uint32_t cnt = 0;
+        // exclusive prefixes over the digits, in digit order: thread t holds digits DPT*t .. DPT*t+DPT-1
+        uint32_t cnt[DPT], tot[DPT], csum = 0, tsum = 0;
 #pragma unroll
-        for (int k = 0; k < kWavesPerBlock; ++k) cnt += woff[k][t];
+        for (int j = 0; j < DPT; ++j) {
+            const int d = DPT * t + j;
+            uint32_t c = 0;
+#pragma unroll
+            for (int k = 0; k < kWavesPerBlock; ++k) c += woff[k][d];
+            cnt[j] = c; csum += c;
+            tot[j] = row_total[d]; tsum += tot[j];
+        }
         uint32_t all;
-        const uint32_t digit_base = block_exclusive_sum(row_total[t], sm, all);
-        const uint32_t lstart = block_exclusive_sum(cnt, sm, all);           // digit t's run in the sorted tile
-        gdelta[t] = (int32_t)(digit_base + offs[(int64_t)t * nblocks + blockIdx.x]) - (int32_t)lstart;
-        uint32_t run = lstart;
+        uint32_t digit_base = block_exclusive_sum(tsum, sm, all);
+        uint32_t lstart = block_exclusive_sum(csum, sm, all);
 #pragma unroll
-        for (int k = 0; k < kWavesPerBlock; ++k) { const uint32_t c = woff[k][t]; woff[k][t] = run; run += c; }
+        for (int j = 0; j < DPT; ++j) {
+            const int d = DPT * t + j;
+            gdelta[d] = (int32_t)(digit_base + offs[(int64_t)d * nblocks + blockIdx.x]) - (int32_t)lstart;
+            uint32_t run = lstart;
+#pragma unroll
+            for (int k = 0; k < kWavesPerBlock; ++k) { const uint32_t c = woff[k][d]; woff[k][d] = run; run += c; }
+            digit_base += tot[j];
+            lstart += cnt[j];
+        }
     }
     __syncthreads();
 
@@ -243,10 +267,10 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
     for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = base + r * kWave + l;
         const bool valid = i < n;
-        const uint32_t d = (uint32_t)(key[r] >> shift) & (kRadix - 1);
+        const uint32_t d = (uint32_t)(key[r] >> shift) & (R - 1);
         uint64_t peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < kRadixBits; ++b) {
+        for (int b = 0; b < BITS; ++b) {
             const bool bit = (d >> b) & 1u;
             const uint64_t bal = __ballot(bit);
             peers &= bit ? bal : ~bal;
@@ -268,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
         const int lp = r * kBlock + t;
         if (lp < count) {
             const uint64_t k = skey[lp];
-            const int64_t dst = (int64_t)lp + gdelta[(uint32_t)(k >> shift) & (kRadix - 1)];
+            const int64_t dst = (int64_t)lp + gdelta[(uint32_t)(k >> shift) & (R - 1)];
             kout[dst] = k;
             vout[dst] = sval[lp];
         }
