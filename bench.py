@@ -161,7 +161,7 @@ def main():
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
     if use_let:
         eng.upload(pos[mine], vel[mine], mass[mine])  # this rank's bodies, resident in HBM from here on
-        overlap = a.let_overlap == "on" or (a.let_overlap == "auto" and world >= 4 and a.backend == "nccl")
+        overlap = a.let_overlap == "on" or (a.let_overlap == "auto" and world >= 4)
         stepper = LetStepper(eng, rank, world, let_cap=1 << 14, device=dev, overlap=overlap)
         cap = stepper.autotune()                      # block size from the measured LET sizes (untimed)
     else:

@@ -271,6 +271,10 @@ class LetStepper:
             out = torch.empty(self.recv.numel(), dtype=self.recv.dtype)
             dist.all_to_all_single(out, self.send.cpu())
             self.recv.copy_(out)
+            if self.overlap:                                  # (nothing to overlap with here; same two launches)
+                self.eng.let_walk_local()
+                self.eng.let_walk_remote(integrate)
+                return
         elif dist.is_initialized() and self.overlap:
             # block q of send -> block rank of q's recv, on the collective's own stream; the local-tree
             # walk does not need it, the second walk launch waits for it
