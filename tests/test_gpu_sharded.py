@@ -7,6 +7,15 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
 import gpu_nbody_simulation_amd as G  # noqa: E402
 from gpu_nbody_simulation_amd import initial_conditions as IC  # noqa: E402
 from gpu_nbody_simulation_amd.distributed import wrap_device_f32  # noqa: E402
@@ -74,7 +83,8 @@ def test_bench_exchange_path_on_real_rccl_single_rank(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for port, decomposition, extra in ((29533, "replicated", []), (29534, "let", []), (29536, "let", ["--let-overlap", "on"])):
+    for decomposition, extra in (("replicated", []), ("let", []), ("let", ["--let-overlap", "on"])):
+        port = _free_port()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1",
                "--steps", "3", "--warmup", "1", "--n-bodies", "65536", "--max-depth", "16", "--force-sharded",
@@ -104,7 +114,7 @@ def test_bench_let_path_with_three_ranks_sharing_the_gpu(tmp_path):
     assert r1.returncode == 0, r1.stderr[-2000:]
     one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
-           "--master-addr", "127.0.0.1", "--master-port", "29535"] + base + ["--gpus", "3", "--backend", "gloo"]
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + base + ["--gpus", "3", "--backend", "gloo"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -119,7 +129,8 @@ def test_bench_let_path_with_three_ranks_sharing_the_gpu(tmp_path):
     assert abs(d["interactions_per_body"] - one["interactions_per_body"]) <= 1e-3 * one["interactions_per_body"]
     # the replicated decomposition through the same rehearsal path (the box allows 6 processes on the
     # GPU, this test process included, so world sizes stay at 3-4)
-    for extra, world, port in ((["--decomposition", "replicated"], 3, 29537), ([], 4, 29538)):
+    for extra, world in ((["--decomposition", "replicated"], 3), ([], 4)):
+        port = _free_port()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                "--master-addr", "127.0.0.1", "--master-port", str(port)] + base + ["--gpus", str(world), "--backend", "gloo"] + extra
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
