@@ -32,11 +32,14 @@ def main():
     ap.add_argument("--init", default="plummer")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--partition", choices=["hilbert", "orb", "orb-nosnap"], default="orb")
+    ap.add_argument("--theta", type=float, default=0.5)
+    ap.add_argument("--precision", choices=["f32", "mixed"], default="f32")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     n = a.n
     m, p, v = IC.make(a.init, n, 1, quasi_static=True)
-    cfg = dict(theta=0.5, max_depth=21, precision=G.Precision.F32, reference_compat=False)
+    cfg = dict(theta=a.theta, max_depth=21, reference_compat=False,
+               precision=G.Precision.MIXED if a.precision == "mixed" else G.Precision.F32)
     res = {"n": n, "init": a.init, "rows": []}
 
     with G.BarnesHutEngine(G.BhConfig(capacity=n, **cfg)) as e:
