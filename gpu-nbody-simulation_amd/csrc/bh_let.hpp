@@ -193,13 +193,8 @@ __device__ __forceinline__ uint64_t let_packed_counts(const uint64_t (&m)[kItems
 
 __device__ __forceinline__ uint64_t block_exclusive_sum_u64(uint64_t v, uint64_t *smem, uint64_t &total)
 {
-    uint64_t inc = v;
+    const uint64_t inc = wave_inclusive_sum(v);
     const int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const uint64_t o = __shfl_up(inc, d, kWave);
-        if (l >= d) inc += o;
-    }
     if (l == kWave - 1) smem[wave_id()] = inc;
     __syncthreads();
     uint64_t base = 0, tot = 0;

@@ -20,17 +20,44 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
 // ---------------------------------------------------------------------------------------------
-// wave-level inclusive scan (Hillis-Steele over DPP-backed shuffles)
+// wave-level inclusive scan on DPP row shifts and row broadcasts (v_mov_b32_dpp / v_add_u32_dpp):
+// four Hillis-Steele steps inside each row of 16 lanes, then lane 15 of rows 0 and 2 is added to
+// rows 1 and 3, then lane 31 to rows 2 and 3.  A `__shfl_up` step is a ds_bpermute through LDS
+// (~100 cycles); the scans sit on the critical path of every latency-bound kernel of the build
+// (scan_apply2 runs 32 of them in sequence), a DPP step is an ordinary VALU instruction.
 // ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
+{
+    // lanes that have no source (shifted in from outside the row, or rows outside ROW_MASK) read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = dpp_mov<CTRL, ROW_MASK>((uint32_t)u), hi = dpp_mov<CTRL, ROW_MASK>((uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));      // +0.0 where there is no source
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_mov(uint64_t u)
+{
+    const uint32_t lo = dpp_mov<CTRL, ROW_MASK>((uint32_t)u), hi = dpp_mov<CTRL, ROW_MASK>((uint32_t)(u >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+constexpr int kDppShr1 = 0x111, kDppShr2 = 0x112, kDppShr4 = 0x114, kDppShr8 = 0x118;
+constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143, kDppWaveShr1 = 0x138;
+
 template <typename T>
 __device__ __forceinline__ T wave_inclusive_sum(T v)
 {
-    const int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        T o = __shfl_up(v, d, kWave);
-        if (l >= d) v += o;
-    }
+    v += dpp_mov<kDppShr1, 0xF>(v);
+    v += dpp_mov<kDppShr2, 0xF>(v);
+    v += dpp_mov<kDppShr4, 0xF>(v);
+    v += dpp_mov<kDppShr8, 0xF>(v);
+    v += dpp_mov<kDppBcast15, 0xA>(v);
+    v += dpp_mov<kDppBcast31, 0xC>(v);
     return v;
 }
 
@@ -43,13 +70,7 @@ __device__ __forceinline__ d3 operator+(d3 x, const d3 &y) { x += y; return x; }
 template <>
 __device__ __forceinline__ d3 wave_inclusive_sum<d3>(d3 v)
 {
-    const int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        double oa = __shfl_up(v.a, d, kWave), ob = __shfl_up(v.b, d, kWave),
-               oc = __shfl_up(v.c, d, kWave);
-        if (l >= d) { v.a += oa; v.b += ob; v.c += oc; }
-    }
+    v.a = wave_inclusive_sum(v.a); v.b = wave_inclusive_sum(v.b); v.c = wave_inclusive_sum(v.c);
     return v;
 }
 
@@ -75,12 +96,9 @@ __device__ __forceinline__ T block_exclusive_sum(T v, T *smem, T &total)
     }
     __syncthreads();
     total = tot;
-    T exc = inc;
-    // exclusive = inclusive - own (recomputed additively to stay exact for integers and
-    // order-stable for doubles: shift the inclusive value down one lane)
-    T prev = __shfl_up(inc, 1, kWave);
-    exc = (lane_id() == 0) ? zero_of<T>() : prev;
-    return base + exc;
+    // exclusive = the inclusive value of the lane before (lane 0 reads 0): no subtraction, so it stays
+    // exact for integers and order-stable for doubles
+    return base + dpp_mov<kDppWaveShr1, 0xF>(inc);
 }
 
 template <>
@@ -98,8 +116,7 @@ __device__ __forceinline__ d3 block_exclusive_sum<d3>(d3 v, d3 *smem, d3 &total)
     }
     __syncthreads();
     total = tot;
-    d3 prev{__shfl_up(inc.a, 1, kWave), __shfl_up(inc.b, 1, kWave), __shfl_up(inc.c, 1, kWave)};
-    if (lane_id() == 0) prev = zero_of<d3>();
+    const d3 prev{dpp_mov<kDppWaveShr1, 0xF>(inc.a), dpp_mov<kDppWaveShr1, 0xF>(inc.b), dpp_mov<kDppWaveShr1, 0xF>(inc.c)};
     return base + prev;
 }
 
