@@ -123,17 +123,45 @@ __device__ __forceinline__ d3 block_exclusive_sum<d3>(d3 v, d3 *smem, d3 &total)
 // ---------------------------------------------------------------------------------------------
 // min/max reduction of 2-D positions -> partial[block] = {xmin, xmax, ymin, ymax} (fp64)
 // ---------------------------------------------------------------------------------------------
+// (DPP as above; a lane without a source keeps its own value, which is neutral for min and max; the
+// result of the whole wave ends up in lane 63 and is broadcast from there)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_self(double v)
+{
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)u, (int)(uint32_t)u, CTRL, ROW_MASK, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(u >> 32), (int)(uint32_t)(u >> 32), CTRL,
+                                                              ROW_MASK, 0xF, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_bcast63(double v)
+{
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), 63);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
 __device__ __forceinline__ double wave_min(double v)
 {
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) { double o = __shfl_xor(v, d, kWave); v = (o < v) ? o : v; }
-    return v;
+    auto mn = [](double a, double b) { return (b < a) ? b : a; };
+    v = mn(v, dpp_mov_self<kDppShr1, 0xF>(v));
+    v = mn(v, dpp_mov_self<kDppShr2, 0xF>(v));
+    v = mn(v, dpp_mov_self<kDppShr4, 0xF>(v));
+    v = mn(v, dpp_mov_self<kDppShr8, 0xF>(v));
+    v = mn(v, dpp_mov_self<kDppBcast15, 0xA>(v));
+    v = mn(v, dpp_mov_self<kDppBcast31, 0xC>(v));
+    return wave_bcast63(v);
 }
 __device__ __forceinline__ double wave_max(double v)
 {
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) { double o = __shfl_xor(v, d, kWave); v = (v < o) ? o : v; }
-    return v;
+    auto mx = [](double a, double b) { return (a < b) ? b : a; };
+    v = mx(v, dpp_mov_self<kDppShr1, 0xF>(v));
+    v = mx(v, dpp_mov_self<kDppShr2, 0xF>(v));
+    v = mx(v, dpp_mov_self<kDppShr4, 0xF>(v));
+    v = mx(v, dpp_mov_self<kDppShr8, 0xF>(v));
+    v = mx(v, dpp_mov_self<kDppBcast15, 0xA>(v));
+    v = mx(v, dpp_mov_self<kDppBcast31, 0xC>(v));
+    return wave_bcast63(v);
 }
 
 }  // namespace bh
