@@ -5,8 +5,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gpu_nbody_simulation_amd as G
 from gpu_nbody_simulation_amd import initial_conditions as IC
-for init in ("plummer", "uniform"):
-    for n in (65536, 262144, 524288, 1048576, 2097152, 4194304):
+for init in ("plummer",):
+    for n in (131072, 262144, 393216, 524288, 786432, 1048576):
         m, p, v = IC.make(init, n, 1, quasi_static=True)
         out = []
         for val in ("8", "4", "2", "0"):
