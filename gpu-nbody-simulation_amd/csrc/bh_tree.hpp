@@ -142,16 +142,34 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
     double x0 = box[0], x1 = box[1], y0 = box[2], y1 = box[3];
     uint64_t k = 0;
     int state = 0;
-    for (int l = 0; l < Dm; ++l) {
-        const double mx = (x0 + x1) / 2, my = (y0 + y1) / 2;
-        const int c = pick_child(x, y, mx, my);
-        if (HILBERT) {
+    // DetermineChild with two compares instead of four -- !(x < mx) is (x >= mx) -- as long as every
+    // compare is ordered: finite body, finite box.  Anything else (a body at infinity blows the box up,
+    // NaN coordinates) takes the reference's four tests, which send unordered compares to child 3 and so
+    // collapse such bodies into one cell instead of spreading them over a tree of their own.
+    const bool ordered = HILBERT && isfinite(x) && isfinite(y) && isfinite(x0) && isfinite(x1) && isfinite(y0) &&
+                         isfinite(y1);
+    if (ordered) {
+        for (int l = 0; l < Dm; ++l) {
+            const double mx = (x0 + x1) / 2, my = (y0 + y1) / 2;
+            const bool bx = !(x < mx), by = !(y < my);
+            const int c = (bx ? 1 : 0) | (by ? 2 : 0);
             k = (k << 2) | (uint64_t)hilbert_digit(state, c);
             state = hilbert_next(state, c);
-        } else {
-            k = (k << 2) | (uint64_t)c;
+            if (bx) x0 = mx; else x1 = mx;
+            if (by) y0 = my; else y1 = my;
         }
-        descend(c, mx, my, x0, x1, y0, y1);
+    } else {
+        for (int l = 0; l < Dm; ++l) {
+            const double mx = (x0 + x1) / 2, my = (y0 + y1) / 2;
+            const int c = pick_child(x, y, mx, my);
+            if (HILBERT) {
+                k = (k << 2) | (uint64_t)hilbert_digit(state, c);
+                state = hilbert_next(state, c);
+            } else {
+                k = (k << 2) | (uint64_t)c;
+            }
+            descend(c, mx, my, x0, x1, y0, y1);
+        }
     }
     keys[i] = k;
     idx[i] = (uint32_t)i;
