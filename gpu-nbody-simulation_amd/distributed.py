@@ -258,7 +258,7 @@ class LetStepper:
                 dist.all_gather_into_tensor(out, self.lbounds.cpu())
                 self.all_bounds.copy_(out)
             else:
-                dist.all_gather_into_tensor(self.all_bounds, self.lbounds.clone())
+                dist.all_gather_into_tensor(self.all_bounds, self.lbounds)     # (separate buffers: no aliasing)
         else:
             assert self.world == 1
             self.all_bounds.copy_(self.lbounds)
