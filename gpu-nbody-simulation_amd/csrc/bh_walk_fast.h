@@ -15,7 +15,7 @@ struct TreeCounters;
 struct WalkFastArgs {
     const QuadF *quads;        // quad 0 = root
     const NodeAux *aux;        // per node: sorted body range (bucket leaves)
-    const float2 *spos;        // positions in Morton-sorted order
+    const float2 *spos;        // positions in sorted (Hilbert) order
     const float *smass;        // masses in sorted order (bucket leaves only)
     const uint32_t *perm;      // sorted index -> caller index
     float2 *pos, *vel;         // caller-order state (updated when integrate && !to_sorted);

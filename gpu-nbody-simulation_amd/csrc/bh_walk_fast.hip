@@ -2,7 +2,7 @@
 // "fp32").  Replaces computeForcesGpu (project.cu:679-793) and updateAccVelPos
 // (project.cu:819-836); designed for CDNA4 wave64, not translated from them.
 //
-//   * one wavefront = 64 Morton-adjacent bodies, one per lane; the traversal state is
+//   * one wavefront = 64 curve-adjacent (Hilbert order) bodies, one per lane; the traversal state is
 //     wave-uniform, so node reads are scalar loads (through the scalar data cache) broadcast to all
 //     lanes for free -- the reference's per-thread walk re-reads each 96-byte node once per body
 //     (project.cu:726), this reads 20 bytes per node once per wave;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
 
     if (a.ctr->overflow) return;
     // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each
-    // with its own 4 MiB L2.  Giving XCD x the x-th CONTIGUOUS eighth of the Morton order makes
+    // with its own 4 MiB L2.  Giving XCD x the x-th CONTIGUOUS eighth of the sorted order makes
     // every L2 cache one spatial region's subtree instead of the whole tree.  Speed only: any
     // placement gives the same result.
     const uint32_t lb = a.xcd_chunk ? (blockIdx.x & 7u) * a.xcd_chunk + (blockIdx.x >> 3) : blockIdx.x;

@@ -2,7 +2,7 @@
 
 The reference is single-GPU; this is new design.  Stage 1, implemented here:
 every rank holds all bodies and builds the same tree (the build is deterministic, so no tree
-exchange is needed), but walks and integrates only its contiguous share of the MORTON-SORTED
+exchange is needed), but walks and integrates only its contiguous share of the curve-SORTED (Hilbert order)
 bodies -- a compact region of space, so its waves touch few distinct nodes -- and the updated
 shares are exchanged with ONE all_gather per step (positions+velocities, 16 B per body in fp32,
 fixed-size blocks, in place).  Results are bit-identical to the single-GPU run because a body's

@@ -181,7 +181,7 @@ int bh_stats(bh_ctx *ctx, bh_stats_t *out);
 
 /* --- multi-GPU plumbing -----------------------------------------------------------------
  * The reference is single-GPU.  One process per GPU owns a contiguous range [lo, hi) of
- * the Morton-sorted bodies: bh_step then walks and integrates only that range, and the
+ * the sorted (space-filling-curve order) bodies: bh_step then walks and integrates only that range, and the
  * host exchanges the updated ranges (torch.distributed all_gather over RCCL) through the
  * device pointers below.  The exchange buffers stay valid until bh_destroy; element types follow
  * the context's precision (double2/double or float2/float).  bh_device_state exposes the state
