@@ -113,6 +113,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
     asm volatile("" ::"v"(p.x), "v"(p.y));                // take the one-time vmcnt wait here, not per child
     float ax = 0.f, ay = 0.f;
     if (a.part == 2 && valid && (SPLIT == 1 || w == 0)) { const float2 t = a.acc_part[s]; ax = t.x; ay = t.y; }
+    asm volatile("" : "+v"(ax), "+v"(ay));                // (same for this load: no s_waitcnt vmcnt in the loop)
     unsigned long long n_vis = 0, n_int = 0, n_wave = 0;
 
     const QuadF BH_CONSTANT *quads = as_constant(a.quads);
