@@ -60,18 +60,48 @@ def plummer(n: int, seed: int = 1, a: float = 0.02, rmax_over_a: float = 10.0, t
     return _f32(np.full(n, mass)), _f32(out), np.zeros((n, 2))
 
 
-def make(kind: str, n: int, seed: int = 1, quasi_static: bool = False):
+# The reference skips a node whose mass is <= 1e-15 together with its whole subtree (project.cu:617);
+# the fp32 node kernel stores such a node as empty.  Benchmark masses must stay above that cutoff.
+EMPTY_NODE_MASS = 1e-15
+QUASI_STATIC_BODY_MASS = 1e-14     # lightest body of the quasi-static benchmark workloads
+
+
+def make(kind: str, n: int, seed: int = 1, quasi_static: bool = False, drift_cells: float = 0.0,
+         drift_depth: int = 12):
     """quasi_static: the benchmark's mass scale.  The reference has no softening and dt = 1
     (project.cu:29, 633-634).  With unit masses a 10^6-body Plummer sphere has a dynamical time of
     0.35 steps; and whatever the scale, the closest pairs (separations down to ~1e-10 near the
     origin, where fp32 is finest) kick each other by G*m/r^2 per step: measured on MI355X, total
     mass 1e-3 still ejects bodies at 4.7 per step, the root box grows 375x in 23 steps and the
     depth-cap cells turn into buckets -- the benchmark would time that degenerate tree, not the
-    stated distribution.  quasi_static uses total mass 1e-8 (body masses ~1e-14, above the
-    reference's 1e-15 empty-node cutoff, project.cu:617) and velocities <= 1e-9, so every timed
-    step sees the distribution as generated.  The work per step does not depend on the mass scale."""
+    stated distribution.  quasi_static scales PER BODY: every mass is >= 1e-14, i.e. above the
+    reference's 1e-15 empty-node cutoff (project.cu:617) at every N (a fixed TOTAL mass of 1e-8 put
+    the equal Plummer masses below the cutoff from N = 8M up and 39 % of the log-uniform masses at
+    N = 1M: those bodies' leaves were stored as empty and their force evaluations skipped).  Plummer:
+    equal masses 1e-14; uniform: log-uniform 1e-14..1e-11 (the shipped files' three decades).
+    Velocities <= 1e-9, so every timed step sees the distribution as generated.  The work per step
+    does not depend on the mass scale.
+
+    drift_cells > 0 (the DYNAMIC benchmark leg): every body additionally moves ballistically by
+    drift_cells x (the width of a depth-`drift_depth` cell of the root box) per step in a random
+    direction (dt = 1), so a stated fraction of the bodies changes leaf cell -- and sorted rank --
+    every step, while the masses stay too small for close-encounter blow-ups."""
     if kind == "uniform":
-        return uniform(n, seed, total_mass=1e-8, vel_scale=1e-9) if quasi_static else uniform(n, seed)
-    if kind == "plummer":
-        return plummer(n, seed, total_mass=1e-8) if quasi_static else plummer(n, seed)
-    raise ValueError(f"unknown initial condition {kind!r}")
+        if not quasi_static:
+            m, p, v = uniform(n, seed)
+        else:
+            m, p, v = uniform(n, seed, total_mass=None, vel_scale=1e-9)
+            m = _f32(m * (QUASI_STATIC_BODY_MASS / 1e-2))       # 1e-2..1e1 -> 1e-14..1e-11
+    elif kind == "plummer":
+        m, p, v = plummer(n, seed, total_mass=QUASI_STATIC_BODY_MASS * n) if quasi_static else plummer(n, seed)
+    else:
+        raise ValueError(f"unknown initial condition {kind!r}")
+    if quasi_static:
+        assert (m.astype(np.float32) > EMPTY_NODE_MASS).all(), "benchmark masses must exceed the empty-node cutoff"
+    if drift_cells > 0.0 and n > 0:
+        span = float(max(p.max(0) - p.min(0)))
+        cell = 1.2 * span / (1 << drift_depth)                  # root box = bounding box + 10 % on every side
+        r = _rng(seed + 7919)
+        ang = r.uniform(0.0, 2.0 * np.pi, size=n)
+        v = _f32(v + drift_cells * cell * np.stack([np.cos(ang), np.sin(ang)], axis=1))
+    return m, p, v

@@ -166,7 +166,10 @@ def _parse(argv):
         k, _, v = d.partition("=")
         if k not in macros:
             ap.error(f"unknown macro {k}")
-        macros[k] = int(eval(v, {"__builtins__": {}}))     # the reference writes `1000 * 40`
+        try:
+            macros[k] = _macro_value(v)
+        except ValueError:
+            ap.error(f"-D{k}={v}: expected an integer or a product of integers (the reference writes `1000 * 40`)")
     if a.n_bodies is not None:
         macros["N_BODIES"] = a.n_bodies
     if a.n_threads is not None:
@@ -174,6 +177,18 @@ def _parse(argv):
     if a.n_simulations is not None:
         macros["N_SIMULATIONS"] = a.n_simulations
     return a, macros
+
+
+def _macro_value(text: str) -> int:
+    """Value of a -D macro as the reference writes them (project.cu:1-11): an integer literal or a
+    product of integer literals such as `1000 * 40`, optionally parenthesised.  Nothing is evaluated."""
+    t = text.strip()
+    while t.startswith("(") and t.endswith(")"):
+        t = t[1:-1].strip()
+    value = 1
+    for factor in t.split("*"):
+        value *= int(factor.strip(), 10)               # ValueError on anything but a decimal integer
+    return value
 
 
 def main(argv=None) -> int:

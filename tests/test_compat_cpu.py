@@ -53,6 +53,13 @@ def test_project_argument_parsing():
     assert mac == {"N_BODIES": 40000, "N_THREADS": 32, "N_SIMULATIONS": 10}        # project.cu:1-11
     a, mac = project._parse([])
     assert mac == {"N_BODIES": 40000, "N_THREADS": 1024, "N_SIMULATIONS": 10}
+    assert project._macro_value("(1000 * 40)") == 40000 and project._macro_value(" 7 ") == 7
+    # macro values are parsed, never evaluated: anything but integers and `*` is refused
+    for bad in ("().__class__", "__import__('os')", "2**3", "1+1", "0x10", ""):
+        with pytest.raises(ValueError):
+            project._macro_value(bad)
+    with pytest.raises(SystemExit):
+        project._parse(["-DN_BODIES=().__class__.__base__"])
 
 
 def test_gpu_sweep_collects_bench_lines_and_computes_efficiency(tmp_path):

@@ -25,7 +25,20 @@ def test_plummer_profile():
 
 
 def test_quasi_static_scale():
-    m, p, v = IC.make("plummer", 4096, 1, quasi_static=True)
-    assert abs(m.sum() - 1e-8) < 1e-12 and m.min() > 1e-15
-    m, p, v = IC.make("uniform", 4096, 1, quasi_static=True)
-    assert abs(m.sum() - 1e-8) < 1e-12 and m.min() > 1e-15 and np.abs(v).max() <= 1e-9
+    """Benchmark masses are scaled PER BODY so that none falls to or below the reference's empty-node
+    cutoff 1e-15 (project.cu:617) at any N -- a fixed total mass did from N = 8M up."""
+    for n in (4096, 1 << 20):
+        m, p, v = IC.make("plummer", n, 1, quasi_static=True)
+        assert np.allclose(m, 1e-14, rtol=1e-6) and (m.astype(np.float32) > 1e-15).all() and not v.any()
+        m, p, v = IC.make("uniform", n, 1, quasi_static=True)
+        assert 1e-14 <= m.min() and m.max() <= 1.0001e-11 and (m.astype(np.float32) > 1e-15).all()
+        assert np.abs(v).max() <= 1e-9
+        assert abs(np.log10(m).mean() + 12.5) < 0.05        # still log-uniform over three decades
+
+
+def test_drift_moves_every_body_by_the_stated_number_of_cells():
+    m, p, v = IC.make("plummer", 8192, 1, quasi_static=True, drift_cells=1.0, drift_depth=12)
+    cell = 1.2 * max(p.max(0) - p.min(0)) / 4096
+    assert np.allclose(np.hypot(v[:, 0], v[:, 1]), cell, rtol=1e-5)
+    m0, p0, v0 = IC.make("plummer", 8192, 1, quasi_static=True)
+    assert np.array_equal(p, p0) and np.array_equal(m, m0)
