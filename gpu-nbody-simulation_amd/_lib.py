@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbhgpu.so")
+# BHGPU_LIB: an A/B build variant (python -m gpu_nbody_simulation_amd.build --variant ...), scripts only
+LIB_PATH = os.environ.get("BHGPU_LIB") or os.path.join(HERE, "libbhgpu.so")
 
 ABI_VERSION = 1
 

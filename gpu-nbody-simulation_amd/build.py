@@ -40,28 +40,40 @@ def _stale() -> bool:
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, variant: str | None = None, extra_flags=()) -> str:
+    """variant: build an A/B variant of the library as build/libbhgpu_<variant>.so with extra_flags
+    (scripts/ only: BHGPU_LIB selects it at load time; the product is libbhgpu.so)."""
+    if variant:
+        return _build_to(os.path.join(HERE, "build", f"libbhgpu_{variant}.so"), os.path.join(HERE, "build", variant),
+                         list(extra_flags), verbose)
     if not force and not _stale():
         return LIB
+    return _build_to(LIB, os.path.join(HERE, "build"), [], verbose)
+
+
+def _build_to(lib: str, objdir: str, extra_flags, verbose: bool) -> str:
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []
     for src, extra in UNITS:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall",
-               "-Wno-unused-function", *extra, *os.environ.get("BHGPU_EXTRA_FLAGS", "").split(),
+               "-Wno-unused-function", *extra, *extra_flags, *os.environ.get("BHGPU_EXTRA_FLAGS", "").split(),
                "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)
         objs.append(obj)
-    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:       # python -m gpu_nbody_simulation_amd.build --variant NAME -DFOO=1 ...
+        i = sys.argv.index("--variant")
+        print(build(variant=sys.argv[i + 1], extra_flags=sys.argv[i + 2:], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -45,8 +45,10 @@ struct bh_ctx {
     int64_t internal_cap = 0, node_cap = 0;
     int sort_passes = 0;
     bool state64 = false;          // fp64 state arrays: exact and mixed precision
-    int walk_mode = 0; bool walk_xcd = false; int walk_split = 0;   // 0 = automatic
-    bool sort_wave_rank = true;    // radix_scatter_w (wave-private ranking); BH_SORT_WAVE_RANK=0: radix_scatter
+    int walk_split = 0;            // 0 = automatic
+    int walk_mode = 0; bool walk_xcd = false; int walk_order = 0;   // -DBHGPU_EXPERIMENTS builds only (A/B)
+    bool walk_asm = true;          // BH_WALK_ASM=0: the C++ loop everywhere (A/B)
+    bool sort_wave_rank = true;    // radix_scatter_w (wave-private ranking); experiments: BH_SORT_WAVE_RANK=0
     int build_items = 0;           // 0 = automatic, else keys per thread in the sort / scan kernels (2, 4, 8)
     bool hilbert = false;                // fp32 mode: Hilbert-ordered keys (BH_HILBERT=0 disables, A/B)  // BH_WALK_PIPE / BH_WALK_XCD override (A/B)
     int partial_count = 0;         // > 0: partial[] holds per-workgroup min/max of the current positions
@@ -70,9 +72,11 @@ struct bh_ctx {
     uint64_t *keys_sorted = nullptr;
     uint32_t *perm = nullptr;
     uint32_t *radix_counts = nullptr, *bsum_sort = nullptr, *bsum_u32 = nullptr, *cnt = nullptr;
+#ifdef BHGPU_EXPERIMENTS
     uint32_t *os_ghist = nullptr, *os_status = nullptr, *os_counter = nullptr, *os_err = nullptr;   // onesweep
     int64_t os_status_words = 0;
-    bool sort_onesweep = false;          // BH_SORT_ONESWEEP=1 selects the look-back sort (measured slower, A/B)
+#endif
+    bool sort_onesweep = false;          // experiments: BH_SORT_ONESWEEP=1 selects the look-back sort
     uint64_t *coarse = nullptr;          // fp32: every 256th sorted key
     uint32_t *cell_first = nullptr;      // fp32: rank of a subdivided cell -> its first sorted body
     d3 *terms = nullptr, *bsum_d3 = nullptr;
@@ -220,6 +224,7 @@ int enqueue_build_t(bh_ctx *c)
                                c->box, c->keys[0], c->vals[0], n, Dm);
         const unsigned nbl = blocks_for(n, ITEMS == kItems ? kSortTile : TILE);
         int cur = 0;
+#ifdef BHGPU_EXPERIMENTS
         if (c->sort_onesweep && c->sort_passes > 0) {
             const int P = c->sort_passes;
             const int64_t words = (int64_t)P * nbl * kRadix;
@@ -235,6 +240,7 @@ int enqueue_build_t(bh_ctx *c)
                 cur ^= 1;
             }
         } else
+#endif
         if (c->sort_wave_rank) {
             // default: kSortBits-wide digits, wave-private ranking, digit-sorted write-out
             constexpr int SB = kSortBits, SR = 1 << SB, SI = (ITEMS == kItems ? kSortItems : ITEMS);
@@ -249,7 +255,9 @@ int enqueue_build_t(bh_ctx *c)
                                    (int)nbl);
                 cur ^= 1;
             }
-        } else
+        }
+#ifdef BHGPU_EXPERIMENTS
+        else
         for (int p = 0; p < c->sort_passes; ++p) {
             const int shift = p * kRadixBits;
             hipLaunchKernelGGL((radix_hist<ITEMS == kItems ? kSortItems : ITEMS>), dim3(nbl), dim3(kBlock), 0, st,
@@ -261,6 +269,7 @@ int enqueue_build_t(bh_ctx *c)
                                c->bsum_sort, n, shift, (int)nbl);
             cur ^= 1;
         }
+#endif
         c->keys_sorted = c->keys[cur];
         c->perm = c->vals[cur];
         if constexpr (!EXACT) {
@@ -394,6 +403,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         a.n_trees = c->let_mode ? c->world : 0; a.self_rank = c->let_mode ? c->rank : -1;
         a.part = part; a.acc_part = c->acc_part;
         a.forest_base = c->forest_base; a.let_cap = c->let_cap;
+        a.order_mode = c->walk_order;
         // the register-lane stack holds 64 entries; the walk never needs more than 3*Dm + 2
         const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0 || (3 * c->Dm + 2 > kWave);
         const int mode = c->let_mode ? 0 : c->walk_mode;
@@ -405,7 +415,11 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
             const int64_t groups = (hi - lo + kWave - 1) / kWave;
             split = groups <= 512 ? 8 : groups <= 3072 ? 4 : 1;
         }
-        BH_HIP(c, launch_walk_fast(a, lds, stats, mode, c->walk_xcd, split, c->stream));
+        // hand-scheduled loop: byte offsets into the quad array and the sorted bodies are 32-bit there
+        const int64_t forest_quads = c->let_mode ? c->forest_base + (int64_t)c->world * c->let_cap : c->internal_cap + 1;
+        const bool use_asm = c->walk_asm && !(c->cfg.flags & BH_FLAG_WALK_PORTABLE) &&
+                             forest_quads * (int64_t)sizeof(QuadF) < (1ll << 31) && c->n < (1ll << 28);
+        BH_HIP(c, launch_walk_fast(a, lds, stats, mode, c->walk_xcd, split, use_asm, c->stream));
         if (walk_fast_split_effective(a, lds, mode, split)) per_partial = kWave;
     }
     if (want_partial) c->partial_count = (int)blocks_for(hi - lo, per_partial);
@@ -415,11 +429,15 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
 int check_overflow(bh_ctx *c)
 {
     TreeCounters h{};
-    uint32_t sort_err = 0;
     BH_HIP(c, hipMemcpyAsync(&h, c->ctr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+#ifdef BHGPU_EXPERIMENTS
+    uint32_t sort_err = 0;
     BH_HIP(c, hipMemcpyAsync(&sort_err, c->os_err, sizeof(sort_err), hipMemcpyDeviceToHost, c->stream));
+#endif
     BH_HIP(c, hipStreamSynchronize(c->stream));
+#ifdef BHGPU_EXPERIMENTS
     if (sort_err) return fail(c, BH_ERR_DEVICE, "radix sort look-back timed out (inter-workgroup wait exceeded its bound)");
+#endif
     if (h.overflow || (int64_t)h.n_internal > c->internal_cap)
         return fail(c, BH_ERR_CAPACITY, "tree needs " + std::to_string(1 + 4 * (int64_t)h.n_internal) +
                                         " nodes, node_capacity is " + std::to_string(c->node_cap));
@@ -464,13 +482,18 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     c->compat = cfg->reference_compat != 0;
     c->device = cfg->device;
     c->sort_passes = (2 * c->Dm + kRadixBits - 1) / kRadixBits;
+#ifdef BHGPU_EXPERIMENTS
+    // measured-and-rejected variants: present only in scripts/ A/B builds
     if (const char *e = std::getenv("BH_WALK_PIPE")) c->walk_mode = std::atoi(e);
     if (const char *e = std::getenv("BH_WALK_XCD")) c->walk_xcd = std::atoi(e) != 0;
-    if (const char *e = std::getenv("BH_WALK_SPLIT")) c->walk_split = std::atoi(e);
-    if (const char *e = std::getenv("BH_BUILD_ITEMS")) c->build_items = std::atoi(e);
+    if (const char *e = std::getenv("BH_WALK_ORDER")) c->walk_order = std::atoi(e);
     if (const char *e = std::getenv("BH_SORT_WAVE_RANK")) c->sort_wave_rank = std::atoi(e) != 0;
-    if (const char *e = std::getenv("BH_REORDER_EVERY")) c->reorder_every = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("BH_SORT_ONESWEEP")) c->sort_onesweep = std::atoi(e) != 0;
+#endif
+    if (const char *e = std::getenv("BH_WALK_SPLIT")) c->walk_split = std::atoi(e);
+    if (const char *e = std::getenv("BH_WALK_ASM")) c->walk_asm = std::atoi(e) != 0;
+    if (const char *e = std::getenv("BH_BUILD_ITEMS")) c->build_items = std::atoi(e);
+    if (const char *e = std::getenv("BH_REORDER_EVERY")) c->reorder_every = std::max(0, std::atoi(e));
     c->hilbert = !c->exact;
     if (const char *e = std::getenv("BH_HILBERT")) c->hilbert = !c->exact && std::atoi(e) != 0;
     auto bail = [&](int rc) { g_create_error = c->err; bh_destroy(c); return rc; };
@@ -510,9 +533,12 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     { const size_t nbl = std::max<size_t>(blocks_for(cap, kSortTile), blocks_for(std::min<int64_t>(cap, 1 << 22), kBlock * kSmallItems));
       A(&c->radix_counts, (size_t)(1 << kSortBits) * nbl);
       A(&c->bsum_sort, (1 << kSortBits) + 8);
+#ifdef BHGPU_EXPERIMENTS
       c->os_status_words = (int64_t)kMaxPasses * nbl * kRadix;
       A(&c->os_status, c->os_status_words); A(&c->os_ghist, kMaxPasses * kRadix); A(&c->os_counter, kMaxPasses);
-      A(&c->os_err, 4); }
+      A(&c->os_err, 4);
+#endif
+    }
     A(&c->bsum_u32, std::max<size_t>(blocks_for(cap + 1, kTile), blocks_for(std::min<int64_t>(cap, 1 << 22) + 1, kBlock * kSmallItems)) + 8);
     A(&c->partial, 4 * (std::max<size_t>(1024, blocks_for(cap, kWave)) + 2)); A(&c->box, 4);
     A(&c->ctr, 1);
@@ -527,7 +553,9 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
         A(&c->terms, cap + 1); A(&c->bsum_d3, std::max<size_t>(blocks_for(cap + 1, kTile), blocks_for(std::min<int64_t>(cap, 1 << 22) + 1, kBlock * kSmallItems)) + 8);
     }
     if (rc) return bail(rc);
+#ifdef BHGPU_EXPERIMENTS
     if (hipMemset(c->os_err, 0, 16) != hipSuccess) { c->err = "hipMemset failed"; return bail(BH_ERR_DEVICE); }
+#endif
     for (auto &e : c->ev_step) if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(BH_ERR_DEVICE); }
     for (auto &e : c->ev_build) if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(BH_ERR_DEVICE); }
     *out = c;

@@ -1,5 +1,6 @@
-// bh_sort.hpp -- stable LSD radix sort of (key, body) pairs for the tree build, and the generic
-// three-kernel exclusive scan it uses.  Included by the engine translation unit only.
+// bh_sort.hpp -- stable LSD radix sort of (key, body) pairs for the tree build.  Included by the
+// engine translation unit only.  Measured-and-rejected variants (the barrier-per-round scatter, the
+// look-back "onesweep" sort) are compiled only with -DBHGPU_EXPERIMENTS (scripts/, never the product).
 //
 //   radix_hist    : counts[digit * nblocks + block] = occurrences of digit in tile `block`
 //   radix_rowscan : one workgroup per digit: exclusive prefix along its row, row total aside
@@ -18,58 +19,6 @@
 #include "bh_prims.hpp"
 
 namespace bh {
-
-template <typename T>
-__global__ __launch_bounds__(kBlock) void scan_tile_sums(const T *__restrict__ in, T *__restrict__ bsum,
-                                                          int64_t n)
-{
-    __shared__ T sm[kWavesPerBlock + 1];
-    const int64_t base = (int64_t)blockIdx.x * kTile;
-    T s = zero_of<T>();
-#pragma unroll
-    for (int k = 0; k < kItems; ++k) {                      // striped: coalesced, order irrelevant
-        const int64_t i = base + k * kBlock + threadIdx.x;
-        if (i < n) s += in[i];
-    }
-    T tot;
-    (void)block_exclusive_sum(s, sm, tot);
-    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
-}
-
-template <typename T>
-__global__ __launch_bounds__(kBlock) void scan_top(T *__restrict__ bsum, int nb, T *__restrict__ total)
-{
-    __shared__ T sm[kWavesPerBlock + 1];
-    T carry = zero_of<T>();
-    for (int c0 = 0; c0 < nb; c0 += kBlock) {
-        const int i = c0 + threadIdx.x;
-        T v = (i < nb) ? bsum[i] : zero_of<T>();
-        T tot;
-        T ex = block_exclusive_sum(v, sm, tot);
-        if (i < nb) bsum[i] = carry + ex;
-        carry += tot;
-    }
-    if (threadIdx.x == 0 && total) *total = carry;
-}
-
-// in == out allowed.  Row by row (256 consecutive elements per block scan): coalesced accesses.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void scan_apply(const T *in, T *out, const T *__restrict__ bsum,
-                                                      int64_t n)
-{
-    __shared__ T sm[kWavesPerBlock + 1];
-    const int64_t base = (int64_t)blockIdx.x * kTile;
-    T carry = bsum[blockIdx.x];
-#pragma unroll 1
-    for (int k = 0; k < kItems; ++k) {
-        const int64_t i = base + k * kBlock + threadIdx.x;
-        const T v = (i < n) ? in[i] : zero_of<T>();
-        T tot;
-        const T ex = block_exclusive_sum(v, sm, tot);
-        if (i < n) out[i] = carry + ex;
-        carry += tot;
-    }
-}
 
 #ifndef BH_SORT_ITEMS
 #define BH_SORT_ITEMS 8
@@ -126,6 +75,7 @@ __global__ __launch_bounds__(kBlock) void radix_hist(const uint64_t *__restrict_
     for (int d = threadIdx.x; d < R; d += kBlock) counts[(int64_t)d * nblocks + blockIdx.x] = h[d];
 }
 
+#ifdef BHGPU_EXPERIMENTS
 template <int ITEMS>
 __global__ __launch_bounds__(kBlock) void radix_scatter(const uint64_t *__restrict__ kin,
                                                          const uint32_t *__restrict__ vin,
@@ -184,6 +134,8 @@ __global__ __launch_bounds__(kBlock) void radix_scatter(const uint64_t *__restri
         __syncthreads();
     }
 }
+
+#endif  // BHGPU_EXPERIMENTS
 
 // ---- scatter with wave-private ranking --------------------------------------------------------------
 // radix_scatter above synchronises the workgroup three times per round of 256 keys (24 barriers per
@@ -299,6 +251,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
     }
 }
 
+#ifdef BHGPU_EXPERIMENTS
 // =================================================================================================
 // Single-kernel-per-pass variant ("onesweep": chained scan with decoupled look-back, Adinets &
 // Merrill 2022), 2 + P launches instead of 3P.  MEASURED AND NOT THE DEFAULT (BH_SORT_ONESWEEP=1
@@ -463,5 +416,7 @@ __global__ __launch_bounds__(kBlock) void radix_onesweep(const uint64_t *__restr
         __syncthreads();
     }
 }
+
+#endif  // BHGPU_EXPERIMENTS
 
 }  // namespace bh

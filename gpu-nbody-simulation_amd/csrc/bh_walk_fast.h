@@ -29,6 +29,7 @@ struct WalkFastArgs {
     float G, dt;
     int integrate, to_sorted;
     uint32_t nblocks, xcd_chunk;   // filled by the launcher
+    int32_t order_mode;            // experiment (BH_WALK_ORDER): 0 = blocks in sorted order, 1 = reversed, 2 = strided
     // forest walk (distributed step): besides the local tree (root quad 0) the bodies walk the
     // locally-essential trees received from the peers, whose root quads sit at
     // forest_base + t * let_cap for every t != self_rank, t < n_trees.  n_trees == 0: local tree only.
@@ -45,8 +46,10 @@ struct WalkFastArgs {
 // split: 1 = one wave per 64 bodies; 2/4/8/16 = that many waves share each 64-body group (few bodies).
 // The launch writes one `partial` entry per workgroup: per 256 bodies, or per 64 when split > 1
 // (walk_fast_split_effective tells which applies).
+// use_asm: take the hand-scheduled loop where it applies (32-bit byte offsets into the quad array: the
+// caller checks that the forest is smaller than 2 GiB and the bodies fewer than 2^28).
 hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, int mode, bool xcd, int split,
-                            hipStream_t st);
+                            bool use_asm, hipStream_t st);
 inline bool walk_fast_split_effective(const WalkFastArgs &a, bool lds_stack, int mode, int split)
 {
     return split > 1 && !lds_stack && mode == 0 && a.n_trees <= 56;

@@ -74,6 +74,177 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
     return r;
 }
 
+// ---- hand-scheduled traversal of ONE tree (the default path: register-lane stack, no counters) -------
+// Why assembly: measured on MI355X (scripts/calib/issue_calib.hip, 8 waves per SIMD) a SIMD spends ~4.2
+// cycles per SCALAR instruction, ~2.2 per plain fp32 VALU instruction, ~4.2 per VALU instruction that
+// writes an SGPR pair or reads one as a lane mask (v_cmp, v_cndmask), ~8.3 per v_rsq_f32 / v_readlane_b32;
+// the scalar and the vector stream of different waves overlap.  The compiler's loop (round 1) issued per
+// child 10 VALU + 5 SALU + 3 branches and per quad ~20 more scalar instructions of pop / address / loop
+// control, which made the scalar stream as long as the vector stream.  This loop:
+//   * EXEC holds the stack entry's lane mask for the whole quad and v_cmpx narrows it to the accepting
+//     lanes: no v_cndmask, no s_and of the ballot with the mask, the force math runs under EXEC;
+//   * `open = mask & ~vcc` sets SCC, which is the push decision: 1 SALU + 1 branch for the ~70 % of the
+//     children nobody opens; the leaf test (child == -1) is only reached by the rest;
+//   * the stack pointer lives in m0 (the lane select of v_readlane / v_writelane), the quad address is one
+//     s_mul_i32 feeding the SGPR-offset form of s_load (round 1: s_mul, s_mul_hi, s_add, s_addc);
+//   * pop is s_sub + branch + three v_readlane.
+// Same operations in the same order as eval()/pop_quad() below, so results are bit-identical to the C++
+// loop (tests/test_gpu_fp32.py::test_asm_walk_equals_the_portable_walk).
+// Hazards handled by instruction order (the assembler does not insert wait states into inline assembly):
+// the consumer of v_rsq_f32 (trans) is separated from it by the scalar push logic; the consumer of
+// v_pk_add_f32 (packed) by the empty-cell test; m0 is written at least one instruction before a lane
+// select uses it.
+// Fixed SGPRs: s[36:55] quad record, s[56:57] lane mask, s[58:59] open mask / scratch, s60 quad index,
+// s61 byte offset, s[62:63] EXEC on entry.
+// Fixed VGPRs (the two-dword operands of v_pk_add_f32 need named halves): v[20:21] body position,
+// v[22:23] dx,dy, v24 d2 then w, v25 1/d, v26 scratch, v[28:29] acceleration sums, v30..v32 the stack.
+#ifndef BH_ASM_POP_RFL
+#define BH_ASM_POP_RFL 1       // pop through EXEC = 1 << sp + v_readfirstlane (4.1 cycles each; v_readlane: 8.3)
+#endif
+#ifndef BH_ASM_EXECZ
+#define BH_ASM_EXECZ 0         // skip the force math of a child that no lane accepts
+#endif
+#if BH_ASM_EXECZ
+#define BH_FORCE_HEAD(TAG) "s_cbranch_execz Lskip" TAG "_%=\n v_rsq_f32_e32 v25, v24\n s_nop 0\n"
+#define BH_FORCE_RSQ_EARLY ""
+#define BH_FORCE_TAIL(TAG) "Lskip" TAG "_%=:\n"
+#else
+#define BH_FORCE_HEAD(TAG) ""
+#define BH_FORCE_RSQ_EARLY "v_rsq_f32_e32 v25, v24\n"
+#define BH_FORCE_TAIL(TAG) ""
+#endif
+// v_pk_add_f32 sits ABOVE the empty-cell test: the two scalar instructions of the test are the wait
+// state a packed result needs before it is read (an empty child wastes those 4 cycles)
+// (-DBHGPU_EXPERIMENTS -DBH_ASM_PAD_VALU=1 / -DBH_ASM_PAD_SALU=1: four redundant vector / scalar
+// instructions per child, the sensitivity experiment of DESIGN.md section 6)
+#if !defined(BHGPU_EXPERIMENTS) || !defined(BH_ASM_PAD_VALU)
+#undef BH_ASM_PAD_VALU
+#define BH_ASM_PAD_VALU 0
+#endif
+#if !defined(BHGPU_EXPERIMENTS) || !defined(BH_ASM_PAD_SALU)
+#undef BH_ASM_PAD_SALU
+#define BH_ASM_PAD_SALU 0
+#endif
+#if BH_ASM_PAD_VALU
+#define BH_PAD_V "v_mov_b32_e32 v27, v27\n v_mov_b32_e32 v27, v27\n v_mov_b32_e32 v27, v27\n v_mov_b32_e32 v27, v27\n"
+#else
+#define BH_PAD_V ""
+#endif
+#if BH_ASM_PAD_SALU
+#define BH_PAD_S "s_mov_b32 s35, s35\n s_mov_b32 s35, s35\n s_mov_b32 s35, s35\n s_mov_b32 s35, s35\n"
+#else
+#define BH_PAD_S ""
+#endif
+#define BH_CHILD(XY, MS, TS, CS, TAG)                                                               \
+    "v_pk_add_f32 v[22:23], " XY ", v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n"                           \
+    "s_cmp_eq_u32 " MS ", 0\n"                                                                      \
+    "s_cbranch_scc1 Lnext" TAG "_%=\n"                                                              \
+    "v_mul_f32_e32 v24, v23, v23\n"                                                                 \
+    "v_fmac_f32_e32 v24, v22, v22\n"                                                                \
+    "v_cmpx_lt_f32_e32 vcc, " TS ", v24\n"                                                          \
+    BH_FORCE_RSQ_EARLY                                                                              \
+    "s_andn2_b64 s[58:59], s[56:57], vcc\n"                                                         \
+    "s_cbranch_scc0 Lforce" TAG "_%=\n"                                                             \
+    "s_cmp_eq_u32 " CS ", -1\n"                                                                     \
+    "s_cbranch_scc1 Lforce" TAG "_%=\n"                                                             \
+    "v_writelane_b32 v30, " CS ", m0\n"                                                             \
+    "v_writelane_b32 v31, s58, m0\n"                                                                \
+    "v_writelane_b32 v32, s59, m0\n"                                                                \
+    "s_add_u32 m0, m0, 1\n"                                                                         \
+    "Lforce" TAG "_%=:\n"                                                                           \
+    BH_FORCE_HEAD(TAG)                                                                              \
+    "v_mul_f32_e32 v26, " MS ", v25\n"                                                              \
+    "v_mul_f32_e32 v26, v25, v26\n"                                                                 \
+    "v_mul_f32_e32 v24, v25, v26\n"                                                                 \
+    "v_fmac_f32_e32 v28, v24, v22\n"                                                                \
+    "v_fmac_f32_e32 v29, v24, v23\n"                                                                \
+    BH_PAD_V BH_PAD_S                                                                               \
+    BH_FORCE_TAIL(TAG)                                                                              \
+    "s_mov_b64 exec, s[56:57]\n"                                                                    \
+    "Lnext" TAG "_%=:\n"
+#if BH_ASM_POP_RFL
+#define BH_POP "s_lshl_b64 exec, 1, m0\n v_readfirstlane_b32 s60, v30\n v_readfirstlane_b32 s56, v31\n v_readfirstlane_b32 s57, v32\n"
+#else
+#define BH_POP "v_readlane_b32 s60, v30, m0\n v_readlane_b32 s56, v31, m0\n v_readlane_b32 s57, v32, m0\n"
+#endif
+
+__device__ __forceinline__ void walk_tree_asm(const QuadF BH_CONSTANT *quads, const NodeAux BH_CONSTANT *aux,
+                                              const float2 BH_CONSTANT *cpos, const float BH_CONSTANT *cmass,
+                                              int32_t root, uint64_t everyone, float px, float py, float &ax,
+                                              float &ay)
+{
+    asm volatile(
+        "s_mov_b64 s[62:63], exec\n"
+        "v_mov_b32_e32 v20, %[px]\n"
+        "v_mov_b32_e32 v21, %[py]\n"
+        "v_mov_b32_e32 v28, %[ax]\n"
+        "v_mov_b32_e32 v29, %[ay]\n"
+        "s_mov_b32 m0, 0\n"
+        "s_mov_b32 s60, %[root]\n"
+        "s_mov_b64 s[56:57], %[every]\n"
+        "Lquad_%=:\n"                                           // s60 = quad index >= 0, s[56:57] = lane mask
+        "s_mul_i32 s61, s60, 0x50\n"
+        "s_load_dwordx16 s[36:51], %[quads], s61\n"
+        "s_load_dwordx4 s[52:55], %[quads], s61 offset:0x40\n"
+        "s_mov_b64 exec, s[56:57]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        BH_CHILD("s[36:37]", "s44", "s48", "s52", "0")
+        BH_CHILD("s[38:39]", "s45", "s49", "s53", "1")
+        BH_CHILD("s[40:41]", "s46", "s50", "s54", "2")
+        BH_CHILD("s[42:43]", "s47", "s51", "s55", "3")
+        "Lpop_%=:\n"
+        "s_sub_u32 m0, m0, 1\n"                                 // SCC = borrow: the stack was empty
+        "s_cbranch_scc1 Ldone_%=\n"
+        BH_POP
+        "s_cmp_lt_i32 s60, 0\n"
+        "s_cbranch_scc0 Lquad_%=\n"
+        // ---- bucket reference -(node id) - 2: the cell's bodies one by one for the lanes that reached it
+        //      (self and exactly coincident bodies contribute nothing: d2 > 0 fails); -1 is dropped
+        "s_cmp_eq_u32 s60, -1\n"
+        "s_cbranch_scc1 Lpop_%=\n"
+        "s_sub_i32 s60, -2, s60\n"
+        "s_lshl_b32 s61, s60, 3\n"
+        "s_load_dwordx2 s[58:59], %[aux], s61\n"              // {first sorted body, count}
+        "s_mov_b64 exec, s[56:57]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_cmp_lt_i32 s59, 1\n"
+        "s_cbranch_scc1 Lpop_%=\n"
+        "s_add_u32 s59, s58, s59\n"
+        "Lbody_%=:\n"
+        "s_lshl_b32 s61, s58, 3\n"
+        "s_load_dwordx2 s[36:37], %[cpos], s61\n"
+        "s_lshl_b32 s61, s58, 2\n"
+        "s_load_dword s44, %[cmass], s61\n"
+        "s_add_u32 s58, s58, 1\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_pk_add_f32 v[22:23], s[36:37], v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n"
+        "s_cmp_lt_u32 s58, s59\n"                               // loop condition (and the packed result's wait state)
+        "v_mul_f32_e32 v24, v23, v23\n"
+        "v_fmac_f32_e32 v24, v22, v22\n"
+        "v_cmpx_lt_f32_e32 vcc, 0, v24\n"
+        "v_rsq_f32_e32 v25, v24\n"
+        "s_nop 0\n"                                             // wait state between v_rsq and its use
+        "v_mul_f32_e32 v26, s44, v25\n"
+        "v_mul_f32_e32 v26, v25, v26\n"
+        "v_mul_f32_e32 v24, v25, v26\n"
+        "v_fmac_f32_e32 v28, v24, v22\n"
+        "v_fmac_f32_e32 v29, v24, v23\n"
+        "s_mov_b64 exec, s[56:57]\n"
+        "s_cbranch_scc1 Lbody_%=\n"
+        "s_branch Lpop_%=\n"
+        "Ldone_%=:\n"
+        "s_mov_b64 exec, s[62:63]\n"
+        "v_mov_b32_e32 %[ax], v28\n"
+        "v_mov_b32_e32 %[ay], v29\n"
+        : [ax] "+v"(ax), [ay] "+v"(ay)
+        : [quads] "s"(quads), [aux] "s"(aux), [cpos] "s"(cpos), [cmass] "s"(cmass), [root] "s"(root),
+          [every] "s"(everyone), [px] "v"(px), [py] "v"(py)
+        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+          "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "m0", "vcc", "scc", "memory",
+          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "s35");
+}
+#undef BH_CHILD
+
 constexpr int kLdsStackDepth = 128;   // 3*31+4 entries worst case
 constexpr int kSplitFrontier = 512;   // split walk: frontier entries per level kept in LDS (12 B each, x2)
 constexpr int kSplitRound = 16;       // split walk: quads per wave per round (4 pushes each fill the 64-lane stack)
@@ -86,10 +257,11 @@ constexpr int kSplitRound = 16;       // split walk: quads per wave per round (4
 // a load latency only when an evaluation starts from an empty stack.  (fp32 mode does not need
 // the reference's visiting order, so taking an entry off the stack before the current quad has
 // pushed its children is allowed.)
-template <bool LDS_STACK, bool STATS, int MODE, int SPLIT>
+template <bool LDS_STACK, bool STATS, int MODE, int SPLIT, bool ASM = false>
 __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_kernel(WalkFastArgs a)
 {
     static_assert(SPLIT == 1 || (!LDS_STACK && MODE == 0), "the split walk uses the register-lane stack, loop 0");
+    static_assert(!ASM || (!LDS_STACK && !STATS && MODE == 0 && SPLIT == 1), "the assembly loop is the default one-wave walk");
     __shared__ int32_t s_base[LDS_STACK ? kWavesPerBlock : 1][LDS_STACK ? kLdsStackDepth : 1];
     __shared__ uint64_t s_mask[LDS_STACK ? kWavesPerBlock : 1][LDS_STACK ? kLdsStackDepth : 1];
     // split walk: two frontiers (current / next level), the waves' push counts, the partial sums
@@ -99,11 +271,18 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
     __shared__ float2 f_red[SPLIT > 1 ? SPLIT : 1][SPLIT > 1 ? kWave : 1];
 
     if (a.ctr->overflow) return;
-    // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each
-    // with its own 4 MiB L2.  Giving XCD x the x-th CONTIGUOUS eighth of the sorted order makes
-    // every L2 cache one spatial region's subtree instead of the whole tree.  Speed only: any
-    // placement gives the same result.
-    const uint32_t lb = a.xcd_chunk ? (blockIdx.x & 7u) * a.xcd_chunk + (blockIdx.x >> 3) : blockIdx.x;
+    // Workgroup -> group of bodies.  Measured and rejected (kept in -DBHGPU_EXPERIMENTS builds): an
+    // XCD-aware placement (workgroups are dealt round-robin over the 8 XCDs, each with its own 4 MiB L2;
+    // XCD x takes the x-th CONTIGUOUS eighth of the sorted order) was neutral in round 1 and in round 2
+    // (0.376 vs 0.379 ms); reversed and strided dispatch orders change nothing either (0.378 / 0.384) --
+    // the tail of the launch is not an ordering effect.
+#ifdef BHGPU_EXPERIMENTS
+    uint32_t lb = a.xcd_chunk ? (blockIdx.x & 7u) * a.xcd_chunk + (blockIdx.x >> 3) : blockIdx.x;
+    if (a.order_mode == 1) lb = a.nblocks - 1 - blockIdx.x;                       // reversed
+    else if (a.order_mode == 2) lb = (uint32_t)(((uint64_t)blockIdx.x * 1021u) % a.nblocks);   // strided (nblocks coprime with 1021)
+#else
+    const uint32_t lb = blockIdx.x;
+#endif
     if (lb >= a.nblocks) return;
     const int lane = lane_id(), w = wave_id();
     // SPLIT > 1: every wave of the workgroup holds the SAME 64 bodies
@@ -360,6 +539,10 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
         for (int32_t t = t_first; t < t_end; ++t) {
             if (t >= 0 && t == a.self_rank) continue;
             int32_t base = (t < 0) ? 0 : (int32_t)(a.forest_base + (int64_t)t * a.let_cap);
+            if (ASM) {
+                walk_tree_asm(quads, aux, cpos, cmass, base, everyone, p.x, p.y, ax, ay);
+                continue;
+            }
             uint64_t mask = everyone;
             do {
                 const QuadRegs q = load_quad(quads + base);
@@ -420,7 +603,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
     }
 }
 
-template <bool L, bool S, int M, int SPLIT = 1>
+template <bool L, bool S, int M, int SPLIT = 1, bool ASM = false>
 static hipError_t launch(WalkFastArgs a, bool xcd, hipStream_t st)
 {
     const int64_t cnt = a.hi - a.lo;
@@ -429,18 +612,21 @@ static hipError_t launch(WalkFastArgs a, bool xcd, hipStream_t st)
     a.nblocks = (uint32_t)((cnt + per_group - 1) / per_group);
     a.xcd_chunk = xcd ? (a.nblocks + 7) / 8 : 0;
     const unsigned grid = xcd ? 8 * a.xcd_chunk : a.nblocks;
-    hipLaunchKernelGGL((walk_fast_kernel<L, S, M, SPLIT>), dim3(grid), dim3(SPLIT > 1 ? kWave * SPLIT : kBlock), 0, st, a);
+    hipLaunchKernelGGL((walk_fast_kernel<L, S, M, SPLIT, ASM>), dim3(grid), dim3(SPLIT > 1 ? kWave * SPLIT : kBlock), 0, st, a);
     return hipGetLastError();
 }
 
 template <bool L, bool S>
 static hipError_t launch_mode(const WalkFastArgs &a, int mode, bool xcd, hipStream_t st)
 {
-    switch (mode) {
+#ifdef BHGPU_EXPERIMENTS
+    switch (mode) {                     // the software-pipelined loops of round 1 (slower)
     case 1: return launch<L, S, 1>(a, xcd, st);
     case 2: return launch<L, S, 2>(a, xcd, st);
-    default: return launch<L, S, 0>(a, xcd, st);
+    default: break;
     }
+#endif
+    return launch<L, S, 0>(a, xcd, st);
 }
 
 template <bool S>
@@ -455,8 +641,12 @@ static hipError_t launch_split(const WalkFastArgs &a, int split, bool xcd, hipSt
 }
 
 hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, int mode, bool xcd, int split,
-                            hipStream_t st)
+                            bool use_asm, hipStream_t st)
 {
+    // the hand-scheduled loop serves the default configuration: one wave per 64 bodies, register-lane
+    // stack, no counters; every other variant runs the C++ loops (same operations, same order)
+    if (use_asm && !lds_stack && !stats && mode == 0 && !walk_fast_split_effective(a, lds_stack, mode, split))
+        return launch<false, false, 0, 1, true>(a, xcd, st);
     // the split walk exists for the register-lane stack and loop 0 only; its queue holds 56 roots
     if (split > 1 && !lds_stack && mode == 0 && a.n_trees <= 56)
         return stats ? launch_split<true>(a, split, xcd, st) : launch_split<false>(a, split, xcd, st);

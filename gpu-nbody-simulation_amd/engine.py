@@ -21,6 +21,7 @@ TREE_NODE_DTYPE = np.dtype(
 FLAG_WALK_STATS = 1 << 0
 FLAG_LDS_STACK = 1 << 1
 FLAG_WALK_NO_SPLIT = 1 << 2
+FLAG_WALK_PORTABLE = 1 << 3
 
 
 class Precision(enum.IntEnum):

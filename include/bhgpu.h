@@ -66,6 +66,11 @@ typedef enum bh_precision {
                                            bodies its launch walks (still reproducible run to
                                            run).  Set this to rule that out.                 */
 
+#define BH_FLAG_WALK_PORTABLE (1u << 3) /* fp32 walk: the C++ traversal loop instead of the
+                                           hand-scheduled gfx950 assembly loop.  Same operations
+                                           in the same order -- results are bit-identical; kept
+                                           as the readable statement of the loop and for tests. */
+
 /* Replaces the compile-time configuration of project.cu:1-11, 27-35, 60-62. */
 typedef struct bh_config {
     int64_t  capacity;          /* max bodies (N_BODIES, project.cu:1-3)                    */
