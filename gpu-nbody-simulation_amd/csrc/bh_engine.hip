@@ -441,6 +441,12 @@ int check_overflow(bh_ctx *c)
     if (h.overflow || (int64_t)h.n_internal > c->internal_cap)
         return fail(c, BH_ERR_CAPACITY, "tree needs " + std::to_string(1 + 4 * (int64_t)h.n_internal) +
                                         " nodes, node_capacity is " + std::to_string(c->node_cap));
+    if (h.walk_overflow) {
+        // sticky since the last check (a step in the middle of bh_step(k) counts); reading clears it
+        BH_HIP(c, hipMemset(&c->ctr->walk_overflow, 0, sizeof(uint32_t)));
+        return fail(c, BH_ERR_CAPACITY, "a wavefront of the fp32 walk ran out of its 64 stack entries: the forces of "
+                                        "that step are invalid; create the context with BH_FLAG_LDS_STACK (128 entries)");
+    }
     return BH_OK;
 }
 
@@ -553,6 +559,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
         A(&c->terms, cap + 1); A(&c->bsum_d3, std::max<size_t>(blocks_for(cap + 1, kTile), blocks_for(std::min<int64_t>(cap, 1 << 22) + 1, kBlock * kSmallItems)) + 8);
     }
     if (rc) return bail(rc);
+    if (hipMemset(c->ctr, 0, sizeof(TreeCounters)) != hipSuccess) { c->err = "hipMemset failed"; return bail(BH_ERR_DEVICE); }
 #ifdef BHGPU_EXPERIMENTS
     if (hipMemset(c->os_err, 0, 16) != hipSuccess) { c->err = "hipMemset failed"; return bail(BH_ERR_DEVICE); }
 #endif
@@ -1144,7 +1151,7 @@ int bh_let_build(bh_ctx *c)
     hipLaunchKernelGGL(let_count_kernel, dim3(ntiles), dim3(kBlock), 0, st, c->needmask, c->world, c->ctr,
                        c->internal_cap, c->let_tsum, ntiles);
     hipLaunchKernelGGL(let_rowscan_kernel, dim3(c->world), dim3(kBlock), 0, st, c->let_tsum, ntiles, c->let_ctr,
-                       (uint32_t)c->let_cap);
+                       (uint32_t)c->let_cap, c->ctr, c->internal_cap);
     hipLaunchKernelGGL(let_apply_kernel, dim3(ntiles), dim3(kBlock), 0, st, c->needmask, c->world, c->ctr,
                        c->internal_cap, c->let_tsum, ntiles, c->let_outidx, nq);
     hipLaunchKernelGGL(let_pack_kernel, dim3(blocks_for(nq, kBlock)), dim3(kBlock), 0, st, c->qf, c->needmask,
@@ -1202,6 +1209,7 @@ int bh_let_counts(bh_ctx *c, uint32_t *counts, int32_t *overflow)
     BH_HIP(c, hipStreamSynchronize(c->stream));
     LetCounters h{};
     BH_HIP(c, hipMemcpy(&h, c->let_ctr, sizeof(h), hipMemcpyDeviceToHost));
+    BH_HIP(c, hipMemset(c->let_ctr, 0, sizeof(LetCounters)));        // reading starts a new observation interval
     for (int r = 0; r < c->world; ++r) counts[r] = h.count[r];
     if (overflow) { *overflow = (int32_t)h.overflow; return BH_OK; }   // the caller inspects the flag
     if (h.overflow) return fail(c, BH_ERR_CAPACITY, "a locally-essential tree exceeded let_cap");

@@ -39,8 +39,11 @@ constexpr int kLetBoxParts = 16;   // first step: partial blocks per box
 static_assert(kMaxWorld <= kWave, "let_box_kernel clears one counter per lane");
 
 struct LetCounters {
-    uint32_t count[kMaxWorld];   // quads packed for each peer
-    uint32_t overflow;           // some LET exceeded let_cap
+    uint32_t count[kMaxWorld];   // quads packed for each peer: the LARGEST value of any build since the counters
+                                 // were last read (bh_let_counts) or configured -- a check every N steps must
+                                 // see an overflow or a near-overflow of ANY step in between, not of the last one
+    uint32_t overflow;           // STICKY: some LET exceeded let_cap, or the local tree outgrew node_capacity
+                                 // (its send blocks are then stale), in some build since the last read
     uint32_t pad[3];
 };
 
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(kWave) void let_box_kernel(const double *__restrict
         ylo = (c < ylo) ? c : ylo;  yhi = (yhi < d) ? d : yhi;
     }
     xlo = wave_min(xlo); xhi = wave_max(xhi); ylo = wave_min(ylo); yhi = wave_max(yhi);
-    if (threadIdx.x < kMaxWorld) lc->count[threadIdx.x] = 0;
+    (void)lc;                                              // (sticky: cleared by bh_let_configure / bh_let_counts only)
     if (threadIdx.x != 0) return;
     const double ex = xhi - xlo, ey = yhi - ylo;
     const double span = (ex < ey) ? ey : ex;
@@ -66,7 +69,6 @@ __global__ __launch_bounds__(kWave) void let_box_kernel(const double *__restrict
     box[0] = xlo - pad; box[1] = xhi + pad; box[2] = ylo - pad; box[3] = yhi + pad;
     ctr->n_internal = 0; ctr->overflow = 0;
     ctr->visits = 0; ctr->interactions = 0; ctr->wave_nodes = 0;
-    lc->overflow = 0;
 }
 
 // First step (no partials from a walk yet): min/max of kLetBoxes * kLetBoxParts CONTIGUOUS slices of
@@ -231,7 +233,9 @@ __global__ __launch_bounds__(kBlock) void let_count_kernel(const uint64_t *__res
 
 // one workgroup per peer: exclusive scan of its tile counts; total = LET size
 __global__ __launch_bounds__(kBlock) void let_rowscan_kernel(uint32_t *__restrict__ tsum, int ntiles,
-                                                              LetCounters *lc, uint32_t let_cap)
+                                                              LetCounters *lc, uint32_t let_cap,
+                                                              const TreeCounters *__restrict__ ctr,
+                                                              int64_t internal_cap)
 {
     __shared__ uint32_t sm[kWavesPerBlock + 1];
     uint32_t *row = tsum + (int64_t)blockIdx.x * ntiles;
@@ -245,8 +249,11 @@ __global__ __launch_bounds__(kBlock) void let_rowscan_kernel(uint32_t *__restric
         carry += tot;
     }
     if (threadIdx.x == 0) {
-        lc->count[blockIdx.x] = carry;
+        if (carry > lc->count[blockIdx.x]) lc->count[blockIdx.x] = carry;      // running maximum (one writer per peer)
         if (carry > let_cap) lc->overflow = 1;
+        // a local tree that outgrew node_capacity leaves the send blocks untouched (let_mark / let_pack
+        // return early): the peers would walk the previous step's LET.  Report it where they look.
+        if (ctr->overflow || (int64_t)ctr->n_internal > internal_cap) lc->overflow = 1;
     }
 }
 

@@ -39,6 +39,7 @@
 #include "bh_nodes.hpp"
 #include "bh_bounds.hpp"
 #include "bh_walk_fast.h"
+#include <cstdlib>
 
 namespace bh {
 
@@ -135,7 +136,7 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
 #else
 #define BH_PAD_S ""
 #endif
-#define BH_CHILD(XY, MS, TS, CS, TAG)                                                               \
+#define BH_CHILD(XY, MS, TS, CS, MASK, TAG)                                                         \
     "v_pk_add_f32 v[22:23], " XY ", v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n"                           \
     "s_cmp_eq_u32 " MS ", 0\n"                                                                      \
     "s_cbranch_scc1 Lnext" TAG "_%=\n"                                                              \
@@ -143,7 +144,7 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
     "v_fmac_f32_e32 v24, v22, v22\n"                                                                \
     "v_cmpx_lt_f32_e32 vcc, " TS ", v24\n"                                                          \
     BH_FORCE_RSQ_EARLY                                                                              \
-    "s_andn2_b64 s[58:59], s[56:57], vcc\n"                                                         \
+    "s_andn2_b64 s[58:59], " MASK ", vcc\n"                                                         \
     "s_cbranch_scc0 Lforce" TAG "_%=\n"                                                             \
     "s_cmp_eq_u32 " CS ", -1\n"                                                                     \
     "s_cbranch_scc1 Lforce" TAG "_%=\n"                                                             \
@@ -160,55 +161,102 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
     "v_fmac_f32_e32 v29, v24, v23\n"                                                                \
     BH_PAD_V BH_PAD_S                                                                               \
     BH_FORCE_TAIL(TAG)                                                                              \
-    "s_mov_b64 exec, s[56:57]\n"                                                                    \
+    "s_mov_b64 exec, " MASK "\n"                                                                    \
     "Lnext" TAG "_%=:\n"
 #if BH_ASM_POP_RFL
-#define BH_POP "s_lshl_b64 exec, 1, m0\n v_readfirstlane_b32 s60, v30\n v_readfirstlane_b32 s56, v31\n v_readfirstlane_b32 s57, v32\n"
+#define BH_POP(IDX, LO, HI) "s_lshl_b64 exec, 1, m0\n v_readfirstlane_b32 " IDX ", v30\n v_readfirstlane_b32 " LO ", v31\n v_readfirstlane_b32 " HI ", v32\n"
 #else
-#define BH_POP "v_readlane_b32 s60, v30, m0\n v_readlane_b32 s56, v31, m0\n v_readlane_b32 s57, v32, m0\n"
+#define BH_POP(IDX, LO, HI) "v_readlane_b32 " IDX ", v30, m0\n v_readlane_b32 " LO ", v31, m0\n v_readlane_b32 " HI ", v32, m0\n"
 #endif
 
-__device__ __forceinline__ void walk_tree_asm(const QuadF BH_CONSTANT *quads, const NodeAux BH_CONSTANT *aux,
-                                              const float2 BH_CONSTANT *cpos, const float BH_CONSTANT *cmass,
-                                              int32_t root, uint64_t everyone, float px, float py, float &ax,
-                                              float &ay)
+// Traversal order (shared with the C++ loop below, bit for bit): the root quad alone; then, as long as
+// the stack holds entries: take the top entry A; a bucket reference is served on the spot; otherwise, if
+// another entry B lies below it (and the stack is not deeper than kPairLimit), take B as well, issue the
+// loads of BOTH quads, wait once, evaluate A, then B.  Two quads in flight per wave: a wave spends half
+// of its life waiting for a quad (the scalar data cache serves a record in 400-640 cycles under load
+// whatever its size or alignment, scripts/calib/sload_chase.hip), and with 4 instead of 8 resident waves
+// per SIMD the kernel takes 1.68 times as long -- it is latency- not issue-bound.
+constexpr int kPairLimit = 40;        // pairs only while sp <= 40: 2 pops, <= 8 pushes stay below 64 entries
+constexpr int kSingleLimit = 60;      // one quad at a time: 1 pop, <= 4 pushes; beyond, the walk gives up (flagged)
+
+// returns nonzero if the 64-entry stack would have overflowed (results invalid; the caller raises
+// TreeCounters::walk_overflow and bh_sync reports it -- BH_FLAG_LDS_STACK has 128 entries)
+__device__ __forceinline__ int32_t walk_tree_asm(const QuadF BH_CONSTANT *quads, const NodeAux BH_CONSTANT *aux,
+                                                 const float2 BH_CONSTANT *cpos, const float BH_CONSTANT *cmass,
+                                                 int32_t root, uint64_t everyone, float px, float py, float &ax,
+                                                 float &ay)
 {
+    int32_t ovf;
     asm volatile(
         "s_mov_b64 s[62:63], exec\n"
         "v_mov_b32_e32 v20, %[px]\n"
         "v_mov_b32_e32 v21, %[py]\n"
         "v_mov_b32_e32 v28, %[ax]\n"
         "v_mov_b32_e32 v29, %[ay]\n"
+        "s_mov_b32 %[ovf], 0\n"
         "s_mov_b32 m0, 0\n"
         "s_mov_b32 s60, %[root]\n"
         "s_mov_b64 s[56:57], %[every]\n"
-        "Lquad_%=:\n"                                           // s60 = quad index >= 0, s[56:57] = lane mask
+        "s_mov_b32 s88, 0\n"
+        "s_branch LloadA_%=\n"
+        // ---------------------------------------------------------------- next entries
+        "Lloop_%=:\n"
+        "s_sub_u32 m0, m0, 1\n"                                 // SCC = borrow: the stack was empty
+        "s_cbranch_scc1 Ldone_%=\n"
+        BH_POP("s60", "s56", "s57")
+        "s_cmp_lt_i32 s60, 0\n"
+        "s_cbranch_scc1 Lspecial_%=\n"
+        "s_mov_b32 s88, 0\n"                                    // s88: a second quad (B) is in flight
+        "s_cmp_eq_u32 m0, 0\n"
+        "s_cbranch_scc1 LloadA_%=\n"
+        "s_cmp_gt_u32 m0, 40\n"                                 // kPairLimit
+        "s_cbranch_scc1 Lsingle_%=\n"
+        "s_sub_u32 m0, m0, 1\n"
+        BH_POP("s86", "s84", "s85")
+        "s_cmp_lt_i32 s86, 0\n"
+        "s_cbranch_scc1 Lunpop_%=\n"
+        "s_mov_b32 s88, 1\n"
+        "s_mul_i32 s87, s86, 0x50\n"
+        "s_load_dwordx16 s[64:79], %[quads], s87\n"
+        "s_load_dwordx4 s[80:83], %[quads], s87 offset:0x40\n"
+        "LloadA_%=:\n"                                          // s60 = quad index >= 0, s[56:57] = lane mask
         "s_mul_i32 s61, s60, 0x50\n"
         "s_load_dwordx16 s[36:51], %[quads], s61\n"
         "s_load_dwordx4 s[52:55], %[quads], s61 offset:0x40\n"
         "s_mov_b64 exec, s[56:57]\n"
         "s_waitcnt lgkmcnt(0)\n"
-        BH_CHILD("s[36:37]", "s44", "s48", "s52", "0")
-        BH_CHILD("s[38:39]", "s45", "s49", "s53", "1")
-        BH_CHILD("s[40:41]", "s46", "s50", "s54", "2")
-        BH_CHILD("s[42:43]", "s47", "s51", "s55", "3")
-        "Lpop_%=:\n"
-        "s_sub_u32 m0, m0, 1\n"                                 // SCC = borrow: the stack was empty
-        "s_cbranch_scc1 Ldone_%=\n"
-        BH_POP
-        "s_cmp_lt_i32 s60, 0\n"
-        "s_cbranch_scc0 Lquad_%=\n"
+        BH_CHILD("s[36:37]", "s44", "s48", "s52", "s[56:57]", "A0")
+        BH_CHILD("s[38:39]", "s45", "s49", "s53", "s[56:57]", "A1")
+        BH_CHILD("s[40:41]", "s46", "s50", "s54", "s[56:57]", "A2")
+        BH_CHILD("s[42:43]", "s47", "s51", "s55", "s[56:57]", "A3")
+        "s_cmp_eq_u32 s88, 0\n"
+        "s_cbranch_scc1 Lloop_%=\n"
+        "s_mov_b64 exec, s[84:85]\n"
+        BH_CHILD("s[64:65]", "s72", "s76", "s80", "s[84:85]", "B0")
+        BH_CHILD("s[66:67]", "s73", "s77", "s81", "s[84:85]", "B1")
+        BH_CHILD("s[68:69]", "s74", "s78", "s82", "s[84:85]", "B2")
+        BH_CHILD("s[70:71]", "s75", "s79", "s83", "s[84:85]", "B3")
+        "s_branch Lloop_%=\n"
+        "Lunpop_%=:\n"                                          // B is a bucket reference: leave it on the stack
+        "s_add_u32 m0, m0, 1\n"
+        "s_branch LloadA_%=\n"
+        "Lsingle_%=:\n"
+        "s_cmp_gt_u32 m0, 60\n"                                 // kSingleLimit
+        "s_cbranch_scc0 LloadA_%=\n"
+        "s_mov_b32 %[ovf], 1\n"
+        "s_branch Ldone_%=\n"
         // ---- bucket reference -(node id) - 2: the cell's bodies one by one for the lanes that reached it
         //      (self and exactly coincident bodies contribute nothing: d2 > 0 fails); -1 is dropped
+        "Lspecial_%=:\n"
         "s_cmp_eq_u32 s60, -1\n"
-        "s_cbranch_scc1 Lpop_%=\n"
+        "s_cbranch_scc1 Lloop_%=\n"
         "s_sub_i32 s60, -2, s60\n"
         "s_lshl_b32 s61, s60, 3\n"
         "s_load_dwordx2 s[58:59], %[aux], s61\n"              // {first sorted body, count}
         "s_mov_b64 exec, s[56:57]\n"
         "s_waitcnt lgkmcnt(0)\n"
         "s_cmp_lt_i32 s59, 1\n"
-        "s_cbranch_scc1 Lpop_%=\n"
+        "s_cbranch_scc1 Lloop_%=\n"
         "s_add_u32 s59, s58, s59\n"
         "Lbody_%=:\n"
         "s_lshl_b32 s61, s58, 3\n"
@@ -231,17 +279,20 @@ __device__ __forceinline__ void walk_tree_asm(const QuadF BH_CONSTANT *quads, co
         "v_fmac_f32_e32 v29, v24, v23\n"
         "s_mov_b64 exec, s[56:57]\n"
         "s_cbranch_scc1 Lbody_%=\n"
-        "s_branch Lpop_%=\n"
+        "s_branch Lloop_%=\n"
         "Ldone_%=:\n"
         "s_mov_b64 exec, s[62:63]\n"
         "v_mov_b32_e32 %[ax], v28\n"
         "v_mov_b32_e32 %[ay], v29\n"
-        : [ax] "+v"(ax), [ay] "+v"(ay)
+        : [ax] "+v"(ax), [ay] "+v"(ay), [ovf] "=&s"(ovf)
         : [quads] "s"(quads), [aux] "s"(aux), [cpos] "s"(cpos), [cmass] "s"(cmass), [root] "s"(root),
           [every] "s"(everyone), [px] "v"(px), [py] "v"(py)
-        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
-          "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "m0", "vcc", "scc", "memory",
-          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "s35");
+        : "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+          "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
+          "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",
+          "s84", "s85", "s86", "s87", "s88", "m0", "vcc", "scc", "memory",
+          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32");
+    return ovf;
 }
 #undef BH_CHILD
 
@@ -252,11 +303,9 @@ constexpr int kSplitRound = 16;       // split walk: quads per wave per round (4
 // Per child: one v_cmp decides accept/open/self (see eval); lane masks stay in SGPR pairs; the
 // three-register stack write happens only for nodes that some lane opens (uniform branches).
 //
-// The loop is software-pipelined over two register sets: while quad A is evaluated, the scalar
-// loads of the next stack entry (quad B) are already in flight, and vice versa, so a wave exposes
-// a load latency only when an evaluation starts from an empty stack.  (fp32 mode does not need
-// the reference's visiting order, so taking an entry off the stack before the current quad has
-// pushed its children is allowed.)
+// One wave per 64 bodies takes TWO stack entries per iteration where it can (see walk_tree_asm):
+// fp32 mode does not need the reference's visiting order, so taking an entry off the stack before the
+// quad above it has pushed its children is allowed.
 template <bool LDS_STACK, bool STATS, int MODE, int SPLIT, bool ASM = false>
 __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_kernel(WalkFastArgs a)
 {
@@ -370,6 +419,20 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
         }
     };
 
+    bool stack_overflow = false;
+    auto pop_raw = [&](int32_t &base, uint64_t &mask) {         // sp > 0
+        --sp;
+        if (LDS_STACK) {
+            base = __builtin_amdgcn_readfirstlane(s_base[w][sp]);
+            const uint64_t m = s_mask[w][sp];
+            mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(m >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)m);
+        } else {
+            base = __builtin_amdgcn_readlane(v_base, sp);
+            mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v_hi, sp) << 32) |
+                   (uint32_t)__builtin_amdgcn_readlane(v_lo, sp);
+        }
+    };
     // take the next quad entry off the stack; bucket references (-(node id) - 2) are served on the
     // way; returns false when the stack is empty
     auto pop_quad = [&](int32_t &base, uint64_t &mask) -> bool {
@@ -540,14 +603,41 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
             if (t >= 0 && t == a.self_rank) continue;
             int32_t base = (t < 0) ? 0 : (int32_t)(a.forest_base + (int64_t)t * a.let_cap);
             if (ASM) {
-                walk_tree_asm(quads, aux, cpos, cmass, base, everyone, p.x, p.y, ax, ay);
+                if (walk_tree_asm(quads, aux, cpos, cmass, base, everyone, p.x, p.y, ax, ay)) stack_overflow = true;
                 continue;
             }
-            uint64_t mask = everyone;
-            do {
+            // the C++ statement of walk_tree_asm's loop: same order, same operations
+            {
                 const QuadRegs q = load_quad(quads + base);
-                eval_quad(q, mask);
-            } while (pop_quad(base, mask));
+                eval_quad(q, everyone);
+            }
+            while (sp > 0) {
+                int32_t bA, bB = 0;
+                uint64_t mA, mB = 0;
+                pop_raw(bA, mA);
+                if (bA < 0) {
+                    if (bA <= -2) bucket(-bA - 2, mA);          // -1 (a leaf opened by a NaN) is dropped
+                    continue;
+                }
+                bool two = false;
+                if (sp > 0 && sp <= kPairLimit) {
+                    pop_raw(bB, mB);
+                    if (bB < 0) ++sp;                           // a bucket reference: leave it on the stack
+                    else two = true;
+                } else if (sp > (LDS_STACK ? kLdsStackDepth - 4 : kSingleLimit)) {
+                    stack_overflow = true;
+                    break;
+                }
+                const QuadRegs A = load_quad(quads + bA);
+                if (two) {
+                    const QuadRegs B = load_quad(quads + bB);
+                    eval_quad(A, mA);
+                    eval_quad(B, mB);
+                } else {
+                    eval_quad(A, mA);
+                }
+            }
+            if (stack_overflow) break;
         }
     }
 
@@ -596,6 +686,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
             }
         }
     } else if (a.partial) block_bounds_to_partial(valid, bx, by, a.partial + 4 * (size_t)lb);
+    if (stack_overflow && lane == 0) a.ctr->walk_overflow = 1;
     if (STATS && lane == 0) {
         atomicAdd(&a.ctr->visits, n_vis);
         atomicAdd(&a.ctr->interactions, n_int);
@@ -612,7 +703,13 @@ static hipError_t launch(WalkFastArgs a, bool xcd, hipStream_t st)
     a.nblocks = (uint32_t)((cnt + per_group - 1) / per_group);
     a.xcd_chunk = xcd ? (a.nblocks + 7) / 8 : 0;
     const unsigned grid = xcd ? 8 * a.xcd_chunk : a.nblocks;
-    hipLaunchKernelGGL((walk_fast_kernel<L, S, M, SPLIT, ASM>), dim3(grid), dim3(SPLIT > 1 ? kWave * SPLIT : kBlock), 0, st, a);
+    unsigned lds_pad = 0;
+#ifdef BHGPU_EXPERIMENTS
+    // occupancy experiment: reserving LDS per workgroup lowers the number of resident waves per SIMD
+    // (40 KB -> 4 workgroups per CU = 4 waves per SIMD; 80 KB -> 2)
+    if (const char *e = std::getenv("BH_WALK_LDS_PAD")) lds_pad = (unsigned)std::atoi(e);
+#endif
+    hipLaunchKernelGGL((walk_fast_kernel<L, S, M, SPLIT, ASM>), dim3(grid), dim3(SPLIT > 1 ? kWave * SPLIT : kBlock), lds_pad, st, a);
     return hipGetLastError();
 }
 

@@ -153,6 +153,16 @@ def init_process_group_from_env(backend: str | None = None):
     return rank, local, world
 
 
+def _bind_engine_stream(engine, device) -> None:
+    """The steppers issue torch collectives on torch's CURRENT stream; the engine enqueues its kernels on
+    its own non-blocking stream unless told otherwise, and nothing would order the two (the all_gather
+    could read the boxes before let_bounds has written them, the walk could read a block before the
+    all_to_all has landed).  Put the engine on torch's stream.  Stand-in engines (CPU tests) have no
+    stream."""
+    if device is not None and torch.device(device).type == "cuda" and hasattr(engine, "set_stream"):
+        engine.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+
 class ShardedStepper:
     """step() = local build + walk of the owned sorted range, all_gather, scatter to caller order."""
 
@@ -162,6 +172,8 @@ class ShardedStepper:
         single rank; used by the tests and `bench.py --force-sharded`)."""
         self.eng, self.rank, self.world, self.n = engine, rank, world, n
         self.exchange = world > 1 or force_exchange
+        if self.exchange:
+            _bind_engine_stream(engine, device)
         per = (n + world - 1) // world
         self.chunk = (per + 255) // 256 * 256       # workgroup-aligned, as bh_owned_range computes it
         engine.set_owned_fraction(rank, world)
@@ -220,6 +232,7 @@ class LetStepper:
         ms per rank at N = 1M on 8 ranks); whether the hidden all_to_all is worth more can only be
         measured on a multi-GPU node, so it is off by default."""
         self.eng, self.rank, self.world, self.device = engine, rank, world, device
+        _bind_engine_stream(engine, device)
         self.ids = ids
         self.overlap = overlap and hasattr(engine, "let_walk_local")
         # the received blocks must start at the same quad index on every rank (a sender writes links in
@@ -291,7 +304,9 @@ class LetStepper:
             self.eng.let_forces()
 
     def max_count(self):
-        """(largest LET any rank packed in its last build, whether any overflowed) -- synchronises."""
+        """(largest LET any rank packed in ANY build since the previous call, whether any of those builds
+        overflowed -- a LET beyond let_cap or a local tree beyond node_capacity) -- synchronises; the
+        all_reduce makes every rank see the same answer, so they raise (or re-size) together."""
         counts, ov = self.eng.let_counts(with_overflow=True)
         t = torch.tensor([max(counts), int(ov)], dtype=torch.int64,
                          device="cpu" if self._staged() else self.lbounds.device)

@@ -256,8 +256,10 @@ class BarnesHutEngine:
         self._check(self._lib.bh_let_walk_remote(self._h, 1 if integrate else 0))
 
     def let_counts(self, with_overflow: bool = False):
-        """Quads packed for each peer in the last let_build (waits for the stream).  Raises BhError(-4)
-        when a LET exceeded let_cap, unless with_overflow: then returns (counts, overflow flag)."""
+        """Per peer, the largest LET of any let_build since the previous let_counts / let_configure (waits
+        for the stream), and whether any of those builds overflowed -- a LET beyond let_cap, or a local
+        tree beyond node_capacity.  Reading starts a new interval.  Raises BhError(-4) on overflow, unless
+        with_overflow: then returns (counts, overflow flag)."""
         arr = (C.c_uint32 * self._let_world)()
         if with_overflow:
             ov = C.c_int32()

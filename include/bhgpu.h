@@ -218,8 +218,12 @@ int bh_scatter_sorted(bh_ctx *ctx);
  *   bh_let_walk     -> every local body walks its own tree and the W-1 received LETs, integrate
  * bh_let_pointers exposes the device buffers for the two collectives; block_bytes is the size of
  * one per-peer block (the pointers change when let_cap does).  bh_let_counts waits for the stream and
- * returns the LET sizes of the last build: with overflow == NULL it fails with BH_ERR_CAPACITY if one
- * exceeded let_cap, otherwise it reports that in *overflow and returns BH_OK.  An overflowing LET is
+ * returns, per peer, the LARGEST LET of any build since the previous bh_let_counts (or
+ * bh_let_configure), and whether any of those builds overflowed: with overflow == NULL it fails with
+ * BH_ERR_CAPACITY if one exceeded let_cap, otherwise it reports that in *overflow and returns BH_OK.
+ * The flag is sticky over the interval (a check every N steps sees an overflow of ANY step in
+ * between) and is also raised when the LOCAL tree outgrew node_capacity, because the send blocks are
+ * then left as they were; reading the counters starts a new interval.  An overflowing LET is
  * truncated safely (links past the block are cut), so the step completes but its forces are wrong:
  * check the counts before trusting a run.  bh_let_configure may be called again with the same
  * rank/world and a new let_cap (size the blocks from measured counts).  bh_let_forces =

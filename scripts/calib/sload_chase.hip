@@ -17,8 +17,12 @@
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-// mode 0: scalar loads (x16 + x4); mode 1: one vector load per record (lanes 0..19 one dword each), next
-// index through v_readfirstlane -- the alternative path through the vector L1
+// mode 0: scalar loads (x16 + x4) of 80-byte records; mode 1: one vector load per record (lanes 0..19 one
+// dword each), next index through v_readfirstlane -- the alternative path through the vector L1;
+// mode 2: 64-byte records on 64-byte boundaries, ONE s_load_dwordx16 (one cache line per record);
+// mode 3: the same 64-byte records read as two s_load_dwordx8; mode 4: 128-byte slots, x16 + x4 from offset 0
+// (the 80-byte payload on a 64-byte boundary: two whole lines)
+typedef int v8i __attribute__((ext_vector_type(8)));
 template <int MODE>
 __global__ __launch_bounds__(256) void chase(const int *buf, uint32_t nrec, int steps, uint64_t *out)
 {
@@ -33,6 +37,23 @@ __global__ __launch_bounds__(256) void chase(const int *buf, uint32_t nrec, int 
             const v4i b = *(const v4i CONSTANT *)(p + 64);
             acc += a[3] ^ b[1];
             idx = (uint32_t)a[0] ^ (uint32_t)(b[3] & 0);       // next record; depends on both loads
+        } else if (MODE == 2) {
+            const char CONSTANT *p = (const char CONSTANT *)buf + (size_t)idx * 64;
+            const v16i a = *(const v16i CONSTANT *)p;
+            acc += a[3] ^ a[9];
+            idx = (uint32_t)a[0] ^ (uint32_t)(a[15] & 0);
+        } else if (MODE == 3) {
+            const char CONSTANT *p = (const char CONSTANT *)buf + (size_t)idx * 64;
+            const v8i a = *(const v8i CONSTANT *)p;
+            const v8i b = *(const v8i CONSTANT *)(p + 32);
+            acc += a[3] ^ b[1];
+            idx = (uint32_t)a[0] ^ (uint32_t)(b[7] & 0);
+        } else if (MODE == 4) {
+            const char CONSTANT *p = (const char CONSTANT *)buf + (size_t)idx * 128;
+            const v16i a = *(const v16i CONSTANT *)p;
+            const v4i b = *(const v4i CONSTANT *)(p + 64);
+            acc += a[3] ^ b[1];
+            idx = (uint32_t)a[0] ^ (uint32_t)(b[3] & 0);
         } else {
             const int lane = threadIdx.x & 63;
             int v = 0;
@@ -52,23 +73,31 @@ int main()
     hipMalloc(&d_out, sizeof(uint64_t) * 2 * waves);
     std::vector<uint64_t> h(2 * waves);
     std::mt19937 rng(1);
-    for (size_t bytes : {size_t(8) << 10, size_t(256) << 10, size_t(2) << 20, size_t(16) << 20, size_t(60) << 20, size_t(240) << 20}) {
-        const uint32_t nrec = (uint32_t)(bytes / 80);
-        std::vector<int> host((size_t)nrec * 20);
-        for (uint32_t r = 0; r < nrec; ++r) {
-            for (int k = 0; k < 20; ++k) host[(size_t)r * 20 + k] = (int)rng();
-            host[(size_t)r * 20] = (int)(rng() % nrec);        // dword 0: the next record
-        }
+    for (size_t bytes : {size_t(8) << 10, size_t(2) << 20, size_t(60) << 20}) {
         int *d_buf;
-        hipMalloc(&d_buf, host.size() * 4);
-        hipMemcpy(d_buf, host.data(), host.size() * 4, hipMemcpyHostToDevice);
-        for (int mode = 0; mode < 2; ++mode) {
+        hipMalloc(&d_buf, bytes);
+        const char *names[5] = {"scalar80", "vector80", "s64x16", "s64x8x8", "s128slot"};
+        const int strides[5] = {20, 20, 16, 16, 32};               // dwords per record slot
+        for (int mode = 0; mode < 5; ++mode) {
+            const int stride = strides[mode];
+            const uint32_t nrec = (uint32_t)(bytes / (4 * stride));
+            std::vector<int> host((size_t)nrec * stride);
+            for (uint32_t r = 0; r < nrec; ++r) {
+                for (int k = 0; k < stride; ++k) host[(size_t)r * stride + k] = (int)rng();
+                host[(size_t)r * stride] = (int)(rng() % nrec);    // dword 0: the next record
+            }
+            hipMemcpy(d_buf, host.data(), host.size() * 4, hipMemcpyHostToDevice);
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
             for (int rep = 0; rep < 2; ++rep) {
                 hipEventRecord(e0);
-                if (mode == 0) hipLaunchKernelGGL(chase<0>, dim3(blocks), dim3(256), 0, 0, d_buf, nrec, steps, d_out);
-                else hipLaunchKernelGGL(chase<1>, dim3(blocks), dim3(256), 0, 0, d_buf, nrec, steps, d_out);
+                switch (mode) {
+                case 0: hipLaunchKernelGGL(chase<0>, dim3(blocks), dim3(256), 0, 0, d_buf, nrec, steps, d_out); break;
+                case 1: hipLaunchKernelGGL(chase<1>, dim3(blocks), dim3(256), 0, 0, d_buf, nrec, steps, d_out); break;
+                case 2: hipLaunchKernelGGL(chase<2>, dim3(blocks), dim3(256), 0, 0, d_buf, nrec, steps, d_out); break;
+                case 3: hipLaunchKernelGGL(chase<3>, dim3(blocks), dim3(256), 0, 0, d_buf, nrec, steps, d_out); break;
+                default: hipLaunchKernelGGL(chase<4>, dim3(blocks), dim3(256), 0, 0, d_buf, nrec, steps, d_out); break;
+                }
                 hipEventRecord(e1);
                 hipDeviceSynchronize();
             }
@@ -78,8 +107,8 @@ int main()
             std::vector<double> cyc;
             for (int w = 0; w < waves; ++w) cyc.push_back((double)h[2 * w] / steps);
             std::sort(cyc.begin(), cyc.end());
-            printf("%-7s buffer %8.2f MB  %7.3f ms  cycles/record/wave median %7.1f (p10 %7.1f p90 %7.1f)  %6.2f G records/s\n",
-                   mode == 0 ? "scalar" : "vector", bytes / 1048576.0, ms, cyc[waves / 2], cyc[waves / 10], cyc[waves * 9 / 10],
+            printf("%-8s buffer %8.2f MB  %7.3f ms  cycles/record/wave median %7.1f (p10 %7.1f p90 %7.1f)  %6.2f G records/s\n",
+                   names[mode], bytes / 1048576.0, ms, cyc[waves / 2], cyc[waves / 10], cyc[waves * 9 / 10],
                    (double)waves * steps / (ms * 1e-3) * 1e-9);
             hipEventDestroy(e0); hipEventDestroy(e1);
         }

@@ -1,0 +1,143 @@
+"""BASELINE configurations 4 and 5 at their FULL sizes on one MI355X ("configs_untested").
+
+  C4: N = 4,194,304, theta = 0.5, Plummer, fp32 -- one context, and the 8-rank ORB + locally-essential-
+      tree decomposition emulated by 8 contexts on this GPU (the device code of an 8-GPU run; the two
+      collectives are replaced by device copies);
+  C5: N = 16,777,216, theta = 0.3, fp64 positions / fp32 forces (BH_PRECISION_MIXED) -- the same two ways.
+
+Checked against the oracle (the CPU restatement of project.cu:575-675, uncapped tree, per-body MAC) on a
+4,096-body slice inside the stated tolerances of test_gpu_fp32.py / test_gpu_mixed.py, plus the
+size-independent properties: determinism, tree size = the oracle's depth-21 tree, Newton's third law
+within the multipole error, interaction counts of the slice equal to the oracle's (MAC flips only).
+The LET forest is a (slightly finer) Barnes-Hut evaluation of its own -- cells that straddle two ranks
+become two partial cells -- so it is measured the way test_gpu_let.py does: against the DIRECT SUM on a
+sample of bodies it must be as accurate as the single tree (median error ratio <= 1.2), the LETs must
+fit their blocks with room to spare, and every rank must hold a balanced share.
+Also here: theta = 0.3 with reference_compat = 0 in fp32 and mixed precision at N = 65,536 against the
+uncapped oracle on every body (round 1 covered theta = 0.3 in exact mode and compat mode only)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bh_oracle as O  # noqa: E402
+import gpu_nbody_simulation_amd as G  # noqa: E402
+from gpu_nbody_simulation_amd import initial_conditions as IC  # noqa: E402
+from gpu_nbody_simulation_amd.engine import FLAG_WALK_STATS  # noqa: E402
+from test_gpu_let import EmulatedRanks  # noqa: E402
+
+G_CONST = 6.67e-11
+TOL = {G.Precision.F32: (2e-6, 1e-4, 5e-3), G.Precision.MIXED: (5e-6, 5e-4, 2e-2)}   # median, 99.9 %, max
+
+
+def rel(a, ref):
+    return np.linalg.norm(a - ref, axis=1) / np.linalg.norm(ref, axis=1)
+
+
+def direct_accel(p, m, idx, chunk=1 << 21):
+    """fp64 direct sum (main_approach_1.cpp:53-75 without the m_i factor) for the bodies idx."""
+    out = np.zeros((len(idx), 2))
+    for k, i in enumerate(idx):
+        acc = np.zeros(2)
+        for c0 in range(0, len(p), chunk):
+            d = p[c0:c0 + chunk] - p[i]
+            r2 = (d * d).sum(1)
+            if c0 <= i < c0 + chunk:
+                r2[i - c0] = np.inf
+            acc += (m[c0:c0 + chunk, None] * d / (r2 * np.sqrt(r2))[:, None]).sum(0)
+        out[k] = G_CONST * acc
+    return out
+
+
+def single_context_checks(n, theta, precision, m, p, v, lo):
+    """One context at full size: oracle slice [lo, lo + 4096), properties.  Returns the accelerations."""
+    hi = lo + 4096
+    with G.BarnesHutEngine(G.BhConfig(capacity=n, theta=theta, max_depth=21, precision=precision,
+                                      reference_compat=False, flags=FLAG_WALK_STATS)) as e:
+        e.upload(p, v, m)
+        e.compute_forces()
+        a1 = e.accelerations()
+        st = e.stats()
+        e.compute_forces()
+        a2 = e.accelerations()
+    assert np.array_equal(a1, a2) and np.isfinite(a1).all()                    # deterministic, finite
+    t = O.build_tree(p, m, 0)
+    f, ws = O.compute_forces(t, p, m, theta=theta, compat_self_skip=False, lo=lo, hi=hi, with_stats=True)
+    del t
+    r = rel(a1[lo:hi], f[lo:hi] / m[lo:hi, None])
+    med, p999, mx = TOL[precision]
+    assert np.median(r) <= med and np.quantile(r, 0.999) <= p999 and r.max() <= mx, (np.median(r), r.max())
+    n21 = len(O.build_tree(p, m, 21))
+    assert st.n_nodes == 1 + 4 * st.n_internal == n21                            # the depth-21 oracle tree
+    net = np.abs((m[:, None] * a1).sum(0)).max()                                 # Newton's third law
+    assert net <= 2e-3 * (m[:, None] * np.abs(a1)).sum()
+    # work per body of the whole launch is that of the oracle's slice to the spread between regions
+    assert 0.5 < (st.interactions / n) / (ws.interactions / 4096) < 2.0
+    return a1
+
+
+def emulated_ranks_checks(world, theta, precision, m, p, v, a_single, sample, let_cap):
+    n = len(m)
+    er = EmulatedRanks(m, p, v, world, let_cap=let_cap, theta=theta, max_depth=21, precision=precision,
+                       reference_compat=False)
+    sizes = np.array([len(ix) for ix in er.parts])
+    assert sizes.sum() == n and sizes.max() <= 1.05 * n / world and sizes.min() >= 0.95 * n / world   # ORB balance
+    er.step(integrate=False)
+    counts = np.array([e.let_counts() for e in er.engs])                        # raises on overflow
+    assert counts.max() < 0.75 * let_cap and counts[np.arange(world), np.arange(world)].max() == 0
+    a = er.gather(lambda e: e.accelerations())
+    er.step(integrate=False)
+    assert np.array_equal(a, er.gather(lambda e: e.accelerations()))            # deterministic
+    er.step()                                                                    # one full step stays finite
+    pn = er.gather(lambda e: e.download()[0])
+    er.close()
+    assert np.isfinite(a).all() and np.isfinite(pn).all()
+    ref = direct_accel(p, m, sample)
+    r_let, r_one = rel(a[sample], ref), rel(a_single[sample], ref)
+    assert np.median(r_let) <= 1.2 * np.median(r_one) + 1e-6, (np.median(r_let), np.median(r_one))
+    assert np.quantile(r_let, 0.95) <= 1.5 * np.quantile(r_one, 0.95) + 1e-5
+    # and the forest follows the single tree everywhere to the partial-cell level
+    assert np.median(rel(a, a_single)) < 2e-3
+    return counts
+
+
+def test_config4_four_million_bodies_single_context_and_eight_rank_let():
+    n = 1 << 22
+    m, p, v = IC.make("plummer", n, 1, quasi_static=True)
+    a1 = single_context_checks(n, 0.5, G.Precision.F32, m, p, v, lo=2_000_000)
+    sample = np.random.default_rng(4).choice(n, 192, replace=False)
+    counts = emulated_ranks_checks(8, 0.5, G.Precision.F32, m, p, v, a1, sample, let_cap=16384)
+    assert counts.max() > 100                                                    # LETs are real, and small
+    assert counts.sum(1).max() * 80 < 8e6                                        # < 8 MB leaves a rank per step
+
+
+def test_config5_sixteen_million_bodies_theta_03_mixed_precision():
+    n = 1 << 24
+    m, p, v = IC.make("plummer", n, 1, quasi_static=True)
+    # fp64 positions that are NOT fp32-representable (the point of the configuration)
+    p = p * (1.0 + 3e-9 * np.random.default_rng(1).standard_normal(p.shape))
+    a1 = single_context_checks(n, 0.3, G.Precision.MIXED, m, p, v, lo=9_000_000)
+    sample = np.random.default_rng(5).choice(n, 96, replace=False)
+    emulated_ranks_checks(8, 0.3, G.Precision.MIXED, m, p, v, a1, sample, let_cap=32768)
+
+
+@pytest.mark.parametrize("precision", [G.Precision.F32, G.Precision.MIXED])
+@pytest.mark.parametrize("kind", ["uniform", "plummer"])
+def test_theta_03_without_compat_against_the_uncapped_oracle(kind, precision):
+    n = 65536
+    m, p, v = IC.make(kind, n, 7, quasi_static=True)
+    if precision == G.Precision.MIXED:
+        p = p * (1.0 + 3e-9 * np.random.default_rng(2).standard_normal(p.shape))
+    t = O.build_tree(p, m, 0)
+    f, ws = O.compute_forces(t, p, m, theta=0.3, compat_self_skip=False, with_stats=True)
+    with G.BarnesHutEngine(G.BhConfig(capacity=n, theta=0.3, max_depth=21, precision=precision,
+                                      reference_compat=False, flags=FLAG_WALK_STATS)) as e:
+        e.upload(p, v, m)
+        e.compute_forces()
+        a = e.accelerations()
+        st = e.stats()
+    r = rel(a, f / m[:, None])
+    med, p999, mx = TOL[precision]
+    assert np.median(r) <= med and np.quantile(r, 0.999) <= p999 and r.max() <= mx, (np.median(r), r.max())
+    assert abs(st.interactions - ws.interactions) <= 2e-4 * ws.interactions      # MAC flips only
+    assert st.n_nodes == len(O.build_tree(p, m, 21))

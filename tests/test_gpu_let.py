@@ -170,6 +170,87 @@ def test_let_overflow_is_reported():
     er.close()
 
 
+def _two_clouds(rng, n, gap):
+    """Two Gaussian clouds of n bodies (sigma 0.01) whose centres are `gap` apart: far apart the peer opens
+    only the top of the other tree (a small LET), interpenetrating it opens most of it (a large one)."""
+    a = rng.normal(0.0, 0.01, (n, 2)) + [-gap / 2, 0.0]
+    b = rng.normal(0.0, 0.01, (n, 2)) + [gap / 2, 0.0]
+    return [x.astype(np.float32).astype(np.float64) for x in (a, b)]
+
+
+def test_let_overflow_of_a_middle_step_is_still_reported():
+    """the overflow flag and the counts used to be cleared by every build, so a check every N
+    steps saw the last build only.  Three builds -- small LETs, LETs far beyond let_cap, small again --
+    and ONE read afterwards: it must report the overflow and the largest count; the next interval is clean."""
+    rng = np.random.default_rng(3)
+    n = 6000
+    m = np.full(2 * n, 1e-3)
+    v = np.zeros((2 * n, 2))
+    far, near = _two_clouds(rng, n, 2.0), _two_clouds(rng, n, 0.004)
+    split = lambda pp, w: [np.arange(0, n), np.arange(n, 2 * n)]
+
+    def run(er, states):
+        for st in states:
+            for e, pos in zip(er.engs, st):
+                e.upload(pos, v[:n], m[:n])
+            er.step(integrate=False)
+
+    probe = EmulatedRanks(m, np.concatenate(far), v, 2, let_cap=1 << 15, partition=split, max_depth=21, reference_compat=False)
+    run(probe, [far])
+    small = max(max(e.let_counts()) for e in probe.engs)
+    run(probe, [near])
+    large = max(max(e.let_counts()) for e in probe.engs)
+    probe.close()
+    assert large > 8 * small, (small, large)
+    cap = 2 * small
+    er = EmulatedRanks(m, np.concatenate(far), v, 2, let_cap=cap, partition=split, max_depth=21, reference_compat=False)
+    run(er, [far, near, far])                                  # nothing read in between
+    for e in er.engs:
+        counts, ov = e.let_counts(with_overflow=True)
+        assert ov and max(counts) == pytest.approx(large, rel=0.02) and max(counts) > cap
+    run(er, [far])
+    for e in er.engs:
+        counts, ov = e.let_counts(with_overflow=True)          # reading started a new interval
+        assert not ov and max(counts) <= small
+    er.close()
+
+
+def test_local_tree_overflow_is_reported_through_the_let_counters():
+    """when the local tree outgrows node_capacity, let_mark / let_pack leave the send blocks as
+    they were and the peers would walk stale data; the rank's own LET counters must say so (they are what
+    LetStepper.check() all-reduces)."""
+    rng = np.random.default_rng(4)
+    n = 4000
+    pos = _two_clouds(rng, n, 0.5)
+    m, v = np.full(n, 1e-3), np.zeros((n, 2))
+    dev = torch.device("cuda", 0)
+    engs = [G.BarnesHutEngine(G.BhConfig(capacity=n, precision=G.Precision.F32, max_depth=21, reference_compat=False,
+                                         node_capacity=(4001 if r == 0 else 0))) for r in range(2)]
+    fb = max(e.let_local_quads() for e in engs)
+    bufs = []
+    for r, e in enumerate(engs):
+        e.upload(pos[r], v, m)
+        e.let_configure(r, 2, 4096, fb)
+        lb, ab, sd, rv, nb, k = e.let_pointers()
+        bufs.append((wrap_device(lb, 4 * k, "<f8", dev), wrap_device(ab, 4 * k * 2, "<f8", dev)))
+    for e in engs:
+        e.let_bounds()
+    torch.cuda.synchronize()
+    allb = torch.cat([b[0] for b in bufs])
+    for b in bufs:
+        b[1].copy_(allb)
+    torch.cuda.synchronize()
+    for e in engs:
+        e.let_build()
+    torch.cuda.synchronize()
+    assert engs[0].let_counts(with_overflow=True)[1]             # rank 0: 1,000 quads cannot hold 4,000 bodies
+    assert not engs[1].let_counts(with_overflow=True)[1]
+    with pytest.raises(G.BhError):
+        engs[0].sync()                                           # and bh_sync names the cause
+    for e in engs:
+        e.close()
+
+
 def test_ranks_without_bodies():
     n = 3
     m, p, v = IC.make("uniform", n, 4)
