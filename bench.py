@@ -50,7 +50,10 @@ def parse():
                          "forces (BASELINE config 'fp64 positions / fp32 forces')")
     ap.add_argument("--lds-stack", action="store_true", help="A/B: LDS traversal stack variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the second distribution")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the extra legs (second distribution, dynamic workload, exact fp64 mode)")
+    ap.add_argument("--drift-cells", type=float, default=1.0,
+                    help="dynamic leg: every body drifts this many depth-12 cell widths per step")
     ap.add_argument("--decomposition", choices=["let", "replicated"], default="let",
                     help="multi-GPU scheme (DESIGN.md 9): 'let' = ORB partition, local trees, locally-"
                          "essential-tree exchange (bodies live on one rank only); 'replicated' = every rank "
@@ -112,6 +115,51 @@ def cpu_baseline(mass, pos, theta, sample):
         "interactions_per_body": st.interactions / sample,
         "cpu_model": model,
     }
+
+
+def rank_churn(p0, p1, depth=16):
+    """Fraction of bodies whose rank in the space-filling-curve order, and whose depth-12 cell, changed
+    between two consecutive states (host-side, untimed; Morton order on the first state's root box)."""
+    lo, hi = p0.min(0), p0.max(0)
+    span = float(max(hi - lo))
+    pad = 0.1 * span if span > 0 else 1e-6
+    org, width = lo - pad, (hi - lo) + 2 * pad
+
+    def keys(p):
+        q = np.clip(((p - org) / width * (1 << depth)).astype(np.int64), 0, (1 << depth) - 1)
+        k = np.zeros(len(p), dtype=np.int64)
+        for b in range(depth):
+            k |= ((q[:, 0] >> b) & 1) << (2 * b)
+            k |= ((q[:, 1] >> b) & 1) << (2 * b + 1)
+        return k
+    k0, k1 = keys(p0), keys(p1)
+    r0 = np.empty(len(p0), dtype=np.int64)
+    r1 = np.empty(len(p0), dtype=np.int64)
+    r0[np.argsort(k0, kind="stable")] = np.arange(len(p0))
+    r1[np.argsort(k1, kind="stable")] = np.arange(len(p0))
+    sh = 2 * (depth - 12)
+    return {"rank_changed_frac": float((r0 != r1).mean()), "cell12_changed_frac": float(((k0 >> sh) != (k1 >> sh)).mean()),
+            "median_abs_rank_shift": float(np.median(np.abs(r1 - r0)))}
+
+
+def timed_leg(G, cfg, mass, pos, vel, steps, warmup):
+    """One single-GPU leg: warm-up, K steps enqueued back to back, wall time around them."""
+    with G.BarnesHutEngine(cfg) as e:
+        e.upload(pos, vel, mass)
+        e.step(warmup)
+        e.sync()
+        t0 = time.perf_counter()
+        e.step(steps)
+        e.sync()
+        dt = time.perf_counter() - t0
+        st = e.stats()
+        p0, _ = e.download()
+        e.step(1)
+        p1, _ = e.download()
+    n = len(mass)
+    return {"value": n * steps / dt, "unit": "body-steps/s", "ms_per_step": dt / steps * 1e3, "build_ms": st.build_ms,
+            "walk_ms": st.walk_ms, "keys_ms": st.keys_ms, "sort_ms": st.sort_ms, "scan_ms": st.scan_ms,
+            "nodes_ms": st.nodes_ms}, p0, p1
 
 
 def main():
@@ -239,16 +287,21 @@ def main():
             # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
             # (profiles/latest_walk_traffic.json, written by scripts/summarize_profile.py; counters
             # cannot be read from inside the process)
-            traffic, tsrc = None, None
+            traffic, tsrc, tdig = None, None, None
+            from gpu_nbody_simulation_amd.build import source_digest
+            digest = source_digest()
             try:
                 with open(os.path.join(ROOT, "profiles", "latest_walk_traffic.json")) as fh:
                     tj = json.load(fh)
-                if n == 1 << 20 and a.init == "plummer":
+                tdig = tj.get("source_digest")
+                # only a profile of THESE kernels on THIS workload counts
+                if n == 1 << 20 and a.init == "plummer" and tdig == digest:
                     traffic, tsrc = tj["traffic_bytes"], tj["source"]
             except (OSError, KeyError, ValueError):
                 pass
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                    "traffic_source_digest": tdig, "source_digest": digest,
                     "kernel": "walk_fast_kernel", "kernel_ms": walk_ms,
                     "algorithmic_bytes_per_launch": walk_bytes, "u64_nodes_per_body": u64}
         out = {
@@ -273,18 +326,27 @@ def main():
             # the uniform distribution next to the Plummer one (same N, theta, steps)
             other = "uniform" if a.init == "plummer" else "plummer"
             m2, p2, v2 = IC.make(other, n, a.seed, quasi_static=True)
-            with G.BarnesHutEngine(cfg) as e2:
-                e2.upload(p2, v2, m2)
-                e2.step(a.warmup)
-                e2.sync()
-                t0 = time.perf_counter()
-                e2.step(a.steps)
-                e2.sync()
-                dt2 = time.perf_counter() - t0
-                s2 = e2.stats()
-            out["secondary"] = {"workload": f"{other}_N{n}_theta{a.theta}", "value": n * a.steps / dt2,
-                                "unit": "body-steps/s", "ms_per_step": dt2 / a.steps * 1e3,
-                                "build_ms": s2.build_ms, "walk_ms": s2.walk_ms}
+            leg, _, _ = timed_leg(G, cfg, m2, p2, v2, a.steps, a.warmup)
+            out["secondary"] = {"workload": f"{other}_N{n}_theta{a.theta}", **leg}
+            # The headline workload is quasi-static (bodies do not change cells, so the sort permutation of
+            # every timed step is the identity).  DYNAMIC leg: same N, theta, dtype and distribution, every
+            # body drifting --drift-cells depth-12 cell widths per step in a random direction (masses still
+            # tiny: no close-encounter blow-up); reported with the measured churn of the sorted order.
+            m3, p3, v3 = IC.make(a.init, n, a.seed, quasi_static=True, drift_cells=a.drift_cells)
+            leg, q0, q1 = timed_leg(G, cfg, m3, p3, v3, a.steps, a.warmup)
+            out["dynamic"] = {"workload": f"{a.init}_N{n}_theta{a.theta}_drift{a.drift_cells}cells_per_step",
+                              **leg, **rank_churn(q0, q1)}
+            # The bit-exact fp64 mode (the parity anchor: the reference's own arithmetic, project.cu:38-65):
+            # its throughput at this size (uncapped: max_depth 21) and at BASELINE config 1's size and cap.
+            ex = {}
+            for tag, (nn, md, kind) in {"C3": (n, a.max_depth, a.init), "C1": (1024, 10, "uniform")}.items():
+                me, pe, ve = (mass, pos, vel) if nn == n else IC.make(kind, nn, a.seed, quasi_static=True)
+                cfg_e = G.BhConfig(capacity=nn, theta=a.theta, max_depth=md, precision=G.Precision.F64_EXACT,
+                                   reference_compat=True, device=local)
+                ks = max(3, a.steps // 4) if nn == n else 200
+                leg, _, _ = timed_leg(G, cfg_e, me, pe, ve, ks, 2)
+                ex[tag] = {"workload": f"{kind}_N{nn}_theta{a.theta}_depth{md}_exact_fp64", "steps": ks, **leg}
+            out["secondary_exact"] = ex
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(mass, pos, a.theta, a.cpu_sample)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # BHGPU_LIB: an A/B build variant (python -m gpu_nbody_simulation_amd.build --variant ...), scripts only
 LIB_PATH = os.environ.get("BHGPU_LIB") or os.path.join(HERE, "libbhgpu.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class bh_config(C.Structure):
@@ -43,6 +43,8 @@ class bh_stats_t(C.Structure):
         ("wave_nodes", C.c_uint64),
         ("last_step_ms", C.c_double), ("build_ms", C.c_double), ("walk_ms", C.c_double),
         ("device_bytes", C.c_uint64),
+        ("keys_ms", C.c_double), ("sort_ms", C.c_double), ("scan_ms", C.c_double), ("nodes_ms", C.c_double),
+        ("build_bytes", C.c_uint64), ("walk_bytes", C.c_uint64),
     ]
 
 

@@ -31,6 +31,18 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm; this library has no non-HIP build)")
 
 
+def source_digest() -> str:
+    """Digest of the device sources (csrc/ + the C-ABI header): what a committed profile is stamped with,
+    so that bench.py can tell whether profiles/latest_walk_traffic.json was measured on THESE kernels
+    (there is no .git on the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "bhgpu.h")]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True

@@ -86,7 +86,8 @@ struct bh_ctx {
     LinkD *ld = nullptr;
     QuadF *qf = nullptr;
     NodeAux *aux = nullptr;
-    int32_t *self_node = nullptr, *cell_depth = nullptr;
+    int32_t *self_node = nullptr;
+    uint32_t *com_pending = nullptr;   // exact mode: subdivided children per cell still to be summed
     TreeCounters *ctr = nullptr;
 
     // ownership (multi-GPU): sorted range [lo, hi) = rank's share
@@ -105,6 +106,8 @@ struct bh_ctx {
     // measurement
     std::vector<hipEvent_t> ev;        // pairs around the walk kernel, one pair per step
     hipEvent_t ev_step[2] = {nullptr, nullptr}, ev_build[2] = {nullptr, nullptr};
+    hipEvent_t ev_grp[3] = {nullptr, nullptr, nullptr};   // after keys / sort / scan of the last timed build
+    bool time_groups = false;      // set by bh_step around its last build
     int64_t steps_done = 0;
     int32_t last_nsteps = 0;
     int timed_pairs = 0;
@@ -222,6 +225,7 @@ int enqueue_build_t(bh_ctx *c)
         else
             hipLaunchKernelGGL((keys_kernel<Real2, false>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
                                c->box, c->keys[0], c->vals[0], n, Dm);
+        if (c->time_groups) (void)hipEventRecord(c->ev_grp[0], st);
         const unsigned nbl = blocks_for(n, ITEMS == kItems ? kSortTile : TILE);
         int cur = 0;
 #ifdef BHGPU_EXPERIMENTS
@@ -287,6 +291,7 @@ int enqueue_build_t(bh_ctx *c)
             }
         }
         c->builds += 1;
+        if (c->time_groups) (void)hipEventRecord(c->ev_grp[1], st);
 
         // 4. cells owned by each sorted neighbour pair (+ fp32: sorted copies and prefix-sum terms),
         // 5. their ranks / the prefix sums
@@ -314,16 +319,18 @@ int enqueue_build_t(bh_ctx *c)
         };
         if (ITEMS == kItems && n <= (int64_t)1 << 21) scan_part(std::integral_constant<int, 4>{});
         else scan_part(std::integral_constant<int, ITEMS>{});
+        if (c->time_groups) (void)hipEventRecord(c->ev_grp[2], st);
     } else {
         c->keys_sorted = c->keys[0];
         c->perm = c->vals[0];
+        if (c->time_groups) for (auto e : c->ev_grp) (void)hipEventRecord(e, st);
     }
 
     // 6. nodes (thread 0 writes the root when nothing is subdivided)
     const unsigned nbn = blocks_for(std::max<int64_t>(n, 1), kBlock);
     if constexpr (EXACT) {
         hipLaunchKernelGGL(nodes_exact_kernel, dim3(nbn), dim3(kBlock), 0, st, c->keys_sorted, c->perm, c->cnt, pos,
-                           mass, c->box, n, Dm, c->internal_cap, c->gd, c->ld, c->self_node, c->cell_depth, c->ctr);
+                           mass, c->box, n, Dm, c->internal_cap, c->gd, c->ld, c->self_node, c->com_pending, c->ctr);
     } else {
         // one thread per subdivided cell; I <= (n-1)*Dm and <= internal_cap
         const int64_t span = std::max<int64_t>(1, std::min<int64_t>(c->internal_cap, std::max<int64_t>(n - 1, 0) * (int64_t)std::max(1, Dm)));
@@ -337,12 +344,11 @@ int enqueue_build_t(bh_ctx *c)
                                c->cell_first, c->spos, c->smass, c->box, c->terms, n, Dm, c->cfg.theta,
                                c->internal_cap, c->qf, c->aux, c->ctr);
     }
-    // 7. exact bottom-up mass pass (ComputeMass, project.cu:473-502)
-    if (EXACT && n > 1) {
+    // 7. exact bottom-up mass pass (ComputeMass, project.cu:473-502): one launch, see com_up_kernel
+    if (EXACT && n > 1 && c->internal_cap > 0) {
         const int64_t span = std::min<int64_t>(c->internal_cap, std::max<int64_t>(1, (n - 1) * (int64_t)std::max(1, Dm)));
-        for (int d = Dm - 1; d >= 0; --d)
-            hipLaunchKernelGGL(com_level_kernel, dim3(blocks_for(span, kBlock)), dim3(kBlock), 0, st, c->gd,
-                               c->ld, c->self_node, c->cell_depth, c->ctr, c->internal_cap, d);
+        hipLaunchKernelGGL(com_up_kernel, dim3(blocks_for(span, kBlock)), dim3(kBlock), 0, st, c->gd, c->ld,
+                           c->self_node, c->com_pending, c->ctr, c->internal_cap);
     }
     BH_HIP(c, hipGetLastError());
     c->tree_valid = true;
@@ -404,8 +410,10 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         a.part = part; a.acc_part = c->acc_part;
         a.forest_base = c->forest_base; a.let_cap = c->let_cap;
         a.order_mode = c->walk_order;
-        // the register-lane stack holds 64 entries; the walk never needs more than 3*Dm + 2
-        const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0 || (3 * c->Dm + 2 > kWave);
+        // the register-lane stack holds 128 entries and pairs entries only while the bound of
+        // walk_tree_asm allows it, so it serves every max_depth <= 32; the LDS stack is the flag's variant
+        const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0;
+        a.pair_limit = std::max(0, 120 - 3 * c->Dm);
         const int mode = c->let_mode ? 0 : c->walk_mode;
         // few bodies: several waves per 64-body group (bh_walk_fast.hip).  Measured best factor
         // (scripts/split_sweep.py): 8 up to 32k bodies per launch, 4 up to 192k,
@@ -415,6 +423,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
             const int64_t groups = (hi - lo + kWave - 1) / kWave;
             split = groups <= 512 ? 8 : groups <= 3072 ? 4 : 1;
         }
+        if (3 * c->Dm + 2 > kWave) split = 1;        // the level-synchronous walk's depth-first fallback has 64 entries
         // hand-scheduled loop: byte offsets into the quad array and the sorted bodies are 32-bit there
         const int64_t forest_quads = c->let_mode ? c->forest_base + (int64_t)c->world * c->let_cap : c->internal_cap + 1;
         const bool use_asm = c->walk_asm && !(c->cfg.flags & BH_FLAG_WALK_PORTABLE) &&
@@ -441,12 +450,6 @@ int check_overflow(bh_ctx *c)
     if (h.overflow || (int64_t)h.n_internal > c->internal_cap)
         return fail(c, BH_ERR_CAPACITY, "tree needs " + std::to_string(1 + 4 * (int64_t)h.n_internal) +
                                         " nodes, node_capacity is " + std::to_string(c->node_cap));
-    if (h.walk_overflow) {
-        // sticky since the last check (a step in the middle of bh_step(k) counts); reading clears it
-        BH_HIP(c, hipMemset(&c->ctr->walk_overflow, 0, sizeof(uint32_t)));
-        return fail(c, BH_ERR_CAPACITY, "a wavefront of the fp32 walk ran out of its 64 stack entries: the forces of "
-                                        "that step are invalid; create the context with BH_FLAG_LDS_STACK (128 entries)");
-    }
     return BH_OK;
 }
 
@@ -550,7 +553,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     A(&c->ctr, 1);
     if (c->exact) {
         A(&c->gd, c->node_cap); A(&c->ld, c->node_cap);
-        A(&c->self_node, c->internal_cap + 1); A(&c->cell_depth, c->internal_cap + 1);
+        A(&c->self_node, c->internal_cap + 1); A(&c->com_pending, c->internal_cap + 1);
     } else {
         A(&c->qf, c->internal_cap + 1); A(&c->aux, 4 * (c->internal_cap + 1));
         A(&c->cell_first, c->internal_cap + 1);
@@ -565,6 +568,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
 #endif
     for (auto &e : c->ev_step) if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(BH_ERR_DEVICE); }
     for (auto &e : c->ev_build) if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(BH_ERR_DEVICE); }
+    for (auto &e : c->ev_grp) if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(BH_ERR_DEVICE); }
     *out = c;
     return BH_OK;
 }
@@ -578,6 +582,7 @@ void bh_destroy(bh_ctx *c)
     for (auto e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev_step) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev_build) if (e) (void)hipEventDestroy(e);
+    for (auto e : c->ev_grp) if (e) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -756,7 +761,9 @@ int bh_step(bh_ctx *c, int32_t nsteps)
     BH_HIP(c, hipEventRecord(c->ev_step[0], c->stream));
     for (int s = 0; s < nsteps; ++s) {
         if (s == nsteps - 1) BH_HIP(c, hipEventRecord(c->ev_build[0], c->stream));
+        c->time_groups = (s == nsteps - 1);
         int rc = enqueue_build(c);
+        c->time_groups = false;
         if (rc) return rc;
         if (s == nsteps - 1) BH_HIP(c, hipEventRecord(c->ev_build[1], c->stream));
         if (s < want) BH_HIP(c, hipEventRecord(c->ev[2 * s], c->stream));
@@ -960,6 +967,16 @@ int bh_stats(bh_ctx *c, bh_stats_t *out)
             acc += ms;
         }
         out->walk_ms = c->timed_pairs ? acc / c->timed_pairs : 0.0;
+        BH_HIP(c, hipEventElapsedTime(&ms, c->ev_build[0], c->ev_grp[0])); out->keys_ms = ms;
+        BH_HIP(c, hipEventElapsedTime(&ms, c->ev_grp[0], c->ev_grp[1])); out->sort_ms = ms;
+        BH_HIP(c, hipEventElapsedTime(&ms, c->ev_grp[1], c->ev_grp[2])); out->scan_ms = ms;
+        BH_HIP(c, hipEventElapsedTime(&ms, c->ev_grp[2], c->ev_build[1])); out->nodes_ms = ms;
+        // algorithmic bytes per body of one build: keys 20 (fp64 state: 28), per radix
+        // pass 8 (histogram) + 24 (scatter), prep 76, scans 59, nodes 140 (exact mode: 96-byte geometry+links)
+        const int passes = (2 * c->Dm + kSortBits - 1) / kSortBits;
+        const uint64_t per_body = (c->state64 ? 28u : 20u) + 32u * (uint64_t)passes + 76u + 59u + 140u;
+        out->build_bytes = (uint64_t)c->n * per_body;
+        out->walk_bytes = out->wave_nodes ? (uint64_t)c->n * 44u + out->wave_nodes * 20u : 0u;
     }
     return BH_OK;
 }

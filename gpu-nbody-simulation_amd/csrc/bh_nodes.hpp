@@ -38,8 +38,7 @@ struct NodeAux { int32_t first, count; };
 struct TreeCounters {
     uint32_t n_internal;       // I  (written by the scan)
     uint32_t overflow;         // 1 if I > internal capacity
-    uint32_t walk_overflow;    // 1 if a wave of the fp32 walk ran out of stack entries (results invalid)
-    uint32_t pad;
+    uint32_t pad[2];
     unsigned long long visits, interactions;
     unsigned long long wave_nodes;   // nodes evaluated by wavefronts (one count per wave per node)
 };

@@ -360,7 +360,7 @@ __device__ __forceinline__ int64_t cell_end(const uint64_t *__restrict__ keys, i
 }
 
 // ---- exact-mode nodes kernel: the owner of each subdivided cell writes its four children --------
-// NodeD/LinkD + self_node/cell_depth for the bottom-up pass.  One thread per sorted neighbour pair;
+// NodeD/LinkD + self_node / pending (subdivided children per cell) for the bottom-up pass.  One thread per sorted neighbour pair;
 // a pair that starts a chain of nested cells handles them in turn (the fp32 kernel below runs one
 // thread per cell instead).  Thread 0 also writes the root when nothing is subdivided (n <= 1 or
 // max_depth == 1).
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kBlock) void nodes_exact_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm,
     const uint32_t *__restrict__ off, const double2 *__restrict__ pos, const double *__restrict__ mass,
     const double *__restrict__ box, int64_t n, int Dm, int64_t internal_cap, NodeD *__restrict__ gd,
-    LinkD *__restrict__ ld, int32_t *__restrict__ self_node, int32_t *__restrict__ cell_depth,
+    LinkD *__restrict__ ld, int32_t *__restrict__ self_node, uint32_t *__restrict__ pending,
     TreeCounters *ctr)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -438,8 +438,8 @@ __global__ __launch_bounds__(kBlock) void nodes_exact_kernel(
             gd[0].size = (ex > ey) ? ex : ey;
             ld[0] = LinkD{quad, -1};
             self_node[0] = 0;
-            cell_depth[0] = 0;
         }
+        uint32_t n_sub = 0;                            // subdivided children: what the bottom-up pass waits for
 
         for (int c = 0; c < 4; ++c) {
             const double cx0 = (c & 1) ? mx : x0, cx1 = (c & 1) ? x1 : mx;
@@ -473,11 +473,12 @@ __global__ __launch_bounds__(kBlock) void nodes_exact_kernel(
                 const uint32_t rc = off[bc] + (uint32_t)((d + 1) - (Lpc + 1));
                 child = 1 + 4 * (int32_t)rc;
                 self_node[rc] = node;
-                cell_depth[rc] = d + 1;
+                ++n_sub;
             }
             gd[node] = NodeD{cx, cy, m, size};
             ld[node] = LinkD{child, occ};
         }
+        pending[r] = n_sub;
         // descend into the child that holds body i (the next cell of this owner's chain)
         if (d < dhi) {
             const int c = (int)((key >> (2 * (Dm - 1 - d))) & 3);
@@ -713,30 +714,49 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     }
 }
 
-// ---- exact bottom-up pass: ComputeMass, project.cu:473-502, one launch per depth ----------------
-__global__ __launch_bounds__(kBlock) void com_level_kernel(NodeD *__restrict__ gd,
-                                                            const LinkD *__restrict__ ld,
-                                                            const int32_t *__restrict__ self_node,
-                                                            const int32_t *__restrict__ cell_depth,
-                                                            const TreeCounters *__restrict__ ctr,
-                                                            int64_t internal_cap, int depth)
+// ---- exact bottom-up pass: ComputeMass, project.cu:473-502, ONE launch ---------------------------------
+// The reference recurses (children before parents).  Round 1 ran one launch per depth (9 at the
+// reference's cap, 31 at cap 32), each ~5 us of launch floor.  Here every thread starts at one subdivided
+// cell; a cell whose four children are all leaves (pending == 0 after the node kernel) is summed at once,
+// and the thread then climbs: it decrements its parent's count of unfinished subdivided children and
+// whoever brings it to zero sums the parent.  Each cell is summed by exactly ONE thread, from the stored
+// values of its children in child order 0..3 starting from 0.0 -- the reference's order (project.cu:483-495)
+// -- so the result does not depend on which thread arrives last: bit-identical to the per-level pass.
+// Inter-workgroup visibility (the per-XCD L2s are not coherent): the decrement is an agent-scope
+// acquire-release RMW, the children's values are read with agent-scope loads after it.
+__global__ __launch_bounds__(kBlock) void com_up_kernel(NodeD *__restrict__ gd, const LinkD *__restrict__ ld,
+                                                         const int32_t *__restrict__ self_node,
+                                                         uint32_t *__restrict__ pending,
+                                                         const TreeCounters *__restrict__ ctr, int64_t internal_cap)
 {
-    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint32_t total = ctr->n_internal;
-    if (r >= (int64_t)total || (int64_t)total > internal_cap) return;
-    if (cell_depth[r] != depth) return;
-    const int32_t node = self_node[r];
-    const int32_t quad = 1 + 4 * (int32_t)r;
-    double tot = 0.0, sx = 0.0, sy = 0.0;
+    if (r0 >= (int64_t)total || (int64_t)total > internal_cap) return;
+    if (pending[r0] != 0) return;                     // a descendant's thread will come by
+    uint32_t r = (uint32_t)r0;
+    for (;;) {
+        const int32_t node = self_node[r];
+        const int32_t quad = 1 + 4 * (int32_t)r;
+        double tot = 0.0, sx = 0.0, sy = 0.0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const NodeD ch = gd[quad + c];
-        tot += ch.m;
-        sx += ch.m * ch.cx;
-        sy += ch.m * ch.cy;
+        for (int c = 0; c < 4; ++c) {
+            const double cm = __hip_atomic_load(&gd[quad + c].m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double cx = __hip_atomic_load(&gd[quad + c].cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double cy = __hip_atomic_load(&gd[quad + c].cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tot += cm;
+            sx += cm * cx;
+            sy += cm * cy;
+        }
+        if (tot > 0.0) { sx /= tot; sy /= tot; }
+        __hip_atomic_store(&gd[node].cx, sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&gd[node].cy, sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&gd[node].m, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (r == 0) break;                            // the root
+        const uint32_t parent = (uint32_t)(node - 1) >> 2;      // node = 1 + 4 * parent rank + child index
+        const uint32_t left = __hip_atomic_fetch_sub(&pending[parent], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (left != 1u) break;                        // other subdivided children are still on their way
+        r = parent;
     }
-    if (tot > 0.0) { sx /= tot; sy /= tot; }
-    gd[node].cx = sx; gd[node].cy = sy; gd[node].m = tot;
 }
 
 }  // namespace bh

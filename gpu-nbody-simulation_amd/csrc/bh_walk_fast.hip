@@ -99,9 +99,6 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
 // s61 byte offset, s[62:63] EXEC on entry.
 // Fixed VGPRs (the two-dword operands of v_pk_add_f32 need named halves): v[20:21] body position,
 // v[22:23] dx,dy, v24 d2 then w, v25 1/d, v26 scratch, v[28:29] acceleration sums, v30..v32 the stack.
-#ifndef BH_ASM_POP_RFL
-#define BH_ASM_POP_RFL 1       // pop through EXEC = 1 << sp + v_readfirstlane (4.1 cycles each; v_readlane: 8.3)
-#endif
 #ifndef BH_ASM_EXECZ
 #define BH_ASM_EXECZ 0         // skip the force math of a child that no lane accepts
 #endif
@@ -136,7 +133,9 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
 #else
 #define BH_PAD_S ""
 #endif
-#define BH_CHILD(XY, MS, TS, CS, MASK, TAG)                                                         \
+// PUSHCHK: "" in an iteration that starts with at most 56 entries (two pops, at most eight pushes: every
+// entry it touches sits in lanes of v30..v32), BH_PUSHCHK(TAG) otherwise (entries 64..127 live in v33..v35)
+#define BH_CHILD(XY, MS, TS, CS, MASK, TAG, PUSHCHK)                                                \
     "v_pk_add_f32 v[22:23], " XY ", v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n"                           \
     "s_cmp_eq_u32 " MS ", 0\n"                                                                      \
     "s_cbranch_scc1 Lnext" TAG "_%=\n"                                                              \
@@ -148,9 +147,11 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
     "s_cbranch_scc0 Lforce" TAG "_%=\n"                                                             \
     "s_cmp_eq_u32 " CS ", -1\n"                                                                     \
     "s_cbranch_scc1 Lforce" TAG "_%=\n"                                                             \
+    PUSHCHK                                                                                         \
     "v_writelane_b32 v30, " CS ", m0\n"                                                             \
     "v_writelane_b32 v31, s58, m0\n"                                                                \
     "v_writelane_b32 v32, s59, m0\n"                                                                \
+    "LpushBack" TAG "_%=:\n"                                                                        \
     "s_add_u32 m0, m0, 1\n"                                                                         \
     "Lforce" TAG "_%=:\n"                                                                           \
     BH_FORCE_HEAD(TAG)                                                                              \
@@ -163,88 +164,110 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
     BH_FORCE_TAIL(TAG)                                                                              \
     "s_mov_b64 exec, " MASK "\n"                                                                    \
     "Lnext" TAG "_%=:\n"
-#if BH_ASM_POP_RFL
-#define BH_POP(IDX, LO, HI) "s_lshl_b64 exec, 1, m0\n v_readfirstlane_b32 " IDX ", v30\n v_readfirstlane_b32 " LO ", v31\n v_readfirstlane_b32 " HI ", v32\n"
-#else
-#define BH_POP(IDX, LO, HI) "v_readlane_b32 " IDX ", v30, m0\n v_readlane_b32 " LO ", v31, m0\n v_readlane_b32 " HI ", v32, m0\n"
-#endif
+// (the lane select of v_writelane and the shift count of s_lshl_b64 use m0[5:0]: entry k sits in lane k & 63)
+#define BH_PUSHCHK(TAG) "s_bitcmp1_b32 m0, 6\n s_cbranch_scc1 LpushHi" TAG "_%=\n"
+#define BH_PUSH_HI(CS, TAG)                                                                         \
+    "LpushHi" TAG "_%=:\n"                                                                          \
+    "v_writelane_b32 v33, " CS ", m0\n"                                                             \
+    "v_writelane_b32 v34, s58, m0\n"                                                                \
+    "v_writelane_b32 v35, s59, m0\n"                                                                \
+    "s_branch LpushBack" TAG "_%=\n"
+// pop: EXEC = the entry's lane, v_readfirstlane (4.1 cycles each; v_readlane: 8.3)
+#define BH_POP_FAST(IDX, LO, HI)                                                                    \
+    "s_lshl_b64 exec, 1, m0\n"                                                                      \
+    "v_readfirstlane_b32 " IDX ", v30\n v_readfirstlane_b32 " LO ", v31\n v_readfirstlane_b32 " HI ", v32\n"
+#define BH_POP(IDX, LO, HI, TAG)                                                                    \
+    "s_lshl_b64 exec, 1, m0\n"                                                                      \
+    "s_bitcmp1_b32 m0, 6\n"                                                                         \
+    "s_cbranch_scc1 LpopHi" TAG "_%=\n"                                                             \
+    "v_readfirstlane_b32 " IDX ", v30\n v_readfirstlane_b32 " LO ", v31\n v_readfirstlane_b32 " HI ", v32\n" \
+    "LpopBack" TAG "_%=:\n"
+#define BH_POP_HI(IDX, LO, HI, TAG)                                                                 \
+    "LpopHi" TAG "_%=:\n"                                                                           \
+    "v_readfirstlane_b32 " IDX ", v33\n v_readfirstlane_b32 " LO ", v34\n v_readfirstlane_b32 " HI ", v35\n" \
+    "s_branch LpopBack" TAG "_%=\n"
+// one iteration: entries A (and B), loads, evaluation.  SFX distinguishes the two copies' labels.
+#define BH_ITERATION(SFX, POPA, POPB, CHK)                                                          \
+    "s_sub_u32 m0, m0, 1\n"                              /* SCC = borrow: the stack was empty */    \
+    "s_cbranch_scc1 Ldone_%=\n"                                                                     \
+    POPA                                                                                            \
+    "s_cmp_lt_i32 s60, 0\n"                                                                         \
+    "s_cbranch_scc1 Lspecial_%=\n"                                                                  \
+    "s_mov_b32 s88, 0\n"                                 /* s88: a second quad (B) is in flight */  \
+    "s_cmp_eq_u32 m0, 0\n"                                                                          \
+    "s_cbranch_scc1 LloadA" SFX "_%=\n"                                                             \
+    "s_cmp_gt_u32 m0, %[plim]\n"                         /* pairs only while the stack bound allows */ \
+    "s_cbranch_scc1 LloadA" SFX "_%=\n"                                                             \
+    "s_sub_u32 m0, m0, 1\n"                                                                         \
+    POPB                                                                                            \
+    "s_cmp_lt_i32 s86, 0\n"                                                                         \
+    "s_cbranch_scc1 Lunpop" SFX "_%=\n"                                                             \
+    "s_mov_b32 s88, 1\n"                                                                            \
+    "s_mul_i32 s87, s86, 0x50\n"                                                                    \
+    "s_load_dwordx16 s[64:79], %[quads], s87\n"                                                     \
+    "s_load_dwordx4 s[80:83], %[quads], s87 offset:0x40\n"                                          \
+    "LloadA" SFX "_%=:\n"                                /* s60 = quad index >= 0, s[56:57] = mask */ \
+    "s_mul_i32 s61, s60, 0x50\n"                                                                    \
+    "s_load_dwordx16 s[36:51], %[quads], s61\n"                                                     \
+    "s_load_dwordx4 s[52:55], %[quads], s61 offset:0x40\n"                                          \
+    "s_mov_b64 exec, s[56:57]\n"                                                                    \
+    "s_waitcnt lgkmcnt(0)\n"                                                                        \
+    BH_CHILD("s[36:37]", "s44", "s48", "s52", "s[56:57]", SFX "A0", CHK(SFX "A0"))                  \
+    BH_CHILD("s[38:39]", "s45", "s49", "s53", "s[56:57]", SFX "A1", CHK(SFX "A1"))                  \
+    BH_CHILD("s[40:41]", "s46", "s50", "s54", "s[56:57]", SFX "A2", CHK(SFX "A2"))                  \
+    BH_CHILD("s[42:43]", "s47", "s51", "s55", "s[56:57]", SFX "A3", CHK(SFX "A3"))                  \
+    "s_cmp_eq_u32 s88, 0\n"                                                                         \
+    "s_cbranch_scc1 Lloop_%=\n"                                                                     \
+    "s_mov_b64 exec, s[84:85]\n"                                                                    \
+    BH_CHILD("s[64:65]", "s72", "s76", "s80", "s[84:85]", SFX "B0", CHK(SFX "B0"))                  \
+    BH_CHILD("s[66:67]", "s73", "s77", "s81", "s[84:85]", SFX "B1", CHK(SFX "B1"))                  \
+    BH_CHILD("s[68:69]", "s74", "s78", "s82", "s[84:85]", SFX "B2", CHK(SFX "B2"))                  \
+    BH_CHILD("s[70:71]", "s75", "s79", "s83", "s[84:85]", SFX "B3", CHK(SFX "B3"))                  \
+    "s_branch Lloop_%=\n"                                                                           \
+    "Lunpop" SFX "_%=:\n"                                /* B is a bucket reference: leave it there */ \
+    "s_add_u32 m0, m0, 1\n"                                                                         \
+    "s_branch LloadA" SFX "_%=\n"
+#define BH_NOCHK(TAG) ""
 
 // Traversal order (shared with the C++ loop below, bit for bit): the root quad alone; then, as long as
 // the stack holds entries: take the top entry A; a bucket reference is served on the spot; otherwise, if
-// another entry B lies below it (and the stack is not deeper than kPairLimit), take B as well, issue the
+// another entry B lies below it (and the stack is not deeper than pair_limit, see below), take B as well, issue the
 // loads of BOTH quads, wait once, evaluate A, then B.  Two quads in flight per wave: a wave spends half
 // of its life waiting for a quad (the scalar data cache serves a record in 400-640 cycles under load
 // whatever its size or alignment, scripts/calib/sload_chase.hip), and with 4 instead of 8 resident waves
 // per SIMD the kernel takes 1.68 times as long -- it is latency- not issue-bound.
-constexpr int kPairLimit = 40;        // pairs only while sp <= 40: 2 pops, <= 8 pushes stay below 64 entries
-constexpr int kSingleLimit = 60;      // one quad at a time: 1 pop, <= 4 pushes; beyond, the walk gives up (flagged)
-
-// returns nonzero if the 64-entry stack would have overflowed (results invalid; the caller raises
-// TreeCounters::walk_overflow and bh_sync reports it -- BH_FLAG_LDS_STACK has 128 entries)
-__device__ __forceinline__ int32_t walk_tree_asm(const QuadF BH_CONSTANT *quads, const NodeAux BH_CONSTANT *aux,
-                                                 const float2 BH_CONSTANT *cpos, const float BH_CONSTANT *cmass,
-                                                 int32_t root, uint64_t everyone, float px, float py, float &ax,
-                                                 float &ay)
+// Stack bound.  Entries live in six VGPRs addressed by lane: 128 entries.  A depth-first phase that starts
+// from S entries never holds more than S + 3 * Dm + 1 (three waiting siblings per level below the entry
+// taken, four at the last); a pair iteration is entered with at most pair_limit + 1 entries and leaves at
+// most pair_limit + 7.  With pair_limit = 120 - 3 * Dm (60 at max_depth 21, 27 at max_depth 32) the stack
+// never exceeds 128 entries whatever the tree -- the engine passes it in (0 = never pair).
+__device__ __forceinline__ void walk_tree_asm(const QuadF BH_CONSTANT *quads, const NodeAux BH_CONSTANT *aux,
+                                              const float2 BH_CONSTANT *cpos, const float BH_CONSTANT *cmass,
+                                              int32_t root, uint64_t everyone, int32_t pair_limit, float px,
+                                              float py, float &ax, float &ay)
 {
-    int32_t ovf;
     asm volatile(
         "s_mov_b64 s[62:63], exec\n"
         "v_mov_b32_e32 v20, %[px]\n"
         "v_mov_b32_e32 v21, %[py]\n"
         "v_mov_b32_e32 v28, %[ax]\n"
         "v_mov_b32_e32 v29, %[ay]\n"
-        "s_mov_b32 %[ovf], 0\n"
         "s_mov_b32 m0, 0\n"
         "s_mov_b32 s60, %[root]\n"
         "s_mov_b64 s[56:57], %[every]\n"
         "s_mov_b32 s88, 0\n"
-        "s_branch LloadA_%=\n"
+        "s_branch LloadAF_%=\n"                                 // the root quad alone
         // ---------------------------------------------------------------- next entries
         "Lloop_%=:\n"
-        "s_sub_u32 m0, m0, 1\n"                                 // SCC = borrow: the stack was empty
-        "s_cbranch_scc1 Ldone_%=\n"
-        BH_POP("s60", "s56", "s57")
-        "s_cmp_lt_i32 s60, 0\n"
-        "s_cbranch_scc1 Lspecial_%=\n"
-        "s_mov_b32 s88, 0\n"                                    // s88: a second quad (B) is in flight
-        "s_cmp_eq_u32 m0, 0\n"
-        "s_cbranch_scc1 LloadA_%=\n"
-        "s_cmp_gt_u32 m0, 40\n"                                 // kPairLimit
-        "s_cbranch_scc1 Lsingle_%=\n"
-        "s_sub_u32 m0, m0, 1\n"
-        BH_POP("s86", "s84", "s85")
-        "s_cmp_lt_i32 s86, 0\n"
-        "s_cbranch_scc1 Lunpop_%=\n"
-        "s_mov_b32 s88, 1\n"
-        "s_mul_i32 s87, s86, 0x50\n"
-        "s_load_dwordx16 s[64:79], %[quads], s87\n"
-        "s_load_dwordx4 s[80:83], %[quads], s87 offset:0x40\n"
-        "LloadA_%=:\n"                                          // s60 = quad index >= 0, s[56:57] = lane mask
-        "s_mul_i32 s61, s60, 0x50\n"
-        "s_load_dwordx16 s[36:51], %[quads], s61\n"
-        "s_load_dwordx4 s[52:55], %[quads], s61 offset:0x40\n"
-        "s_mov_b64 exec, s[56:57]\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        BH_CHILD("s[36:37]", "s44", "s48", "s52", "s[56:57]", "A0")
-        BH_CHILD("s[38:39]", "s45", "s49", "s53", "s[56:57]", "A1")
-        BH_CHILD("s[40:41]", "s46", "s50", "s54", "s[56:57]", "A2")
-        BH_CHILD("s[42:43]", "s47", "s51", "s55", "s[56:57]", "A3")
-        "s_cmp_eq_u32 s88, 0\n"
-        "s_cbranch_scc1 Lloop_%=\n"
-        "s_mov_b64 exec, s[84:85]\n"
-        BH_CHILD("s[64:65]", "s72", "s76", "s80", "s[84:85]", "B0")
-        BH_CHILD("s[66:67]", "s73", "s77", "s81", "s[84:85]", "B1")
-        BH_CHILD("s[68:69]", "s74", "s78", "s82", "s[84:85]", "B2")
-        BH_CHILD("s[70:71]", "s75", "s79", "s83", "s[84:85]", "B3")
-        "s_branch Lloop_%=\n"
-        "Lunpop_%=:\n"                                          // B is a bucket reference: leave it on the stack
-        "s_add_u32 m0, m0, 1\n"
-        "s_branch LloadA_%=\n"
-        "Lsingle_%=:\n"
-        "s_cmp_gt_u32 m0, 60\n"                                 // kSingleLimit
-        "s_cbranch_scc0 LloadA_%=\n"
-        "s_mov_b32 %[ovf], 1\n"
-        "s_branch Ldone_%=\n"
+        "s_cmp_gt_u32 m0, 56\n"
+        "s_cbranch_scc1 LloopChk_%=\n"
+        BH_ITERATION("F", BH_POP_FAST("s60", "s56", "s57"), BH_POP_FAST("s86", "s84", "s85"), BH_NOCHK)
+        "LloopChk_%=:\n"                                        // more than 56 entries: pushes / pops pick their VGPRs
+        BH_ITERATION("C", BH_POP("s60", "s56", "s57", "A"), BH_POP("s86", "s84", "s85", "B"), BH_PUSHCHK)
+        BH_PUSH_HI("s52", "CA0") BH_PUSH_HI("s53", "CA1") BH_PUSH_HI("s54", "CA2") BH_PUSH_HI("s55", "CA3")
+        BH_PUSH_HI("s80", "CB0") BH_PUSH_HI("s81", "CB1") BH_PUSH_HI("s82", "CB2") BH_PUSH_HI("s83", "CB3")
+        BH_POP_HI("s60", "s56", "s57", "A")
+        BH_POP_HI("s86", "s84", "s85", "B")
         // ---- bucket reference -(node id) - 2: the cell's bodies one by one for the lanes that reached it
         //      (self and exactly coincident bodies contribute nothing: d2 > 0 fails); -1 is dropped
         "Lspecial_%=:\n"
@@ -284,17 +307,17 @@ __device__ __forceinline__ int32_t walk_tree_asm(const QuadF BH_CONSTANT *quads,
         "s_mov_b64 exec, s[62:63]\n"
         "v_mov_b32_e32 %[ax], v28\n"
         "v_mov_b32_e32 %[ay], v29\n"
-        : [ax] "+v"(ax), [ay] "+v"(ay), [ovf] "=&s"(ovf)
+        : [ax] "+v"(ax), [ay] "+v"(ay)
         : [quads] "s"(quads), [aux] "s"(aux), [cpos] "s"(cpos), [cmass] "s"(cmass), [root] "s"(root),
-          [every] "s"(everyone), [px] "v"(px), [py] "v"(py)
+          [every] "s"(everyone), [px] "v"(px), [py] "v"(py), [plim] "s"(pair_limit)
         : "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
           "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
           "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",
           "s84", "s85", "s86", "s87", "s88", "m0", "vcc", "scc", "memory",
-          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32");
-    return ovf;
+          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35");
 }
 #undef BH_CHILD
+#undef BH_ITERATION
 
 constexpr int kLdsStackDepth = 128;   // 3*31+4 entries worst case
 constexpr int kSplitFrontier = 512;   // split walk: frontier entries per level kept in LDS (12 B each, x2)
@@ -349,7 +372,8 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
     const float2 BH_CONSTANT *cpos = as_constant(a.spos);
     const float BH_CONSTANT *cmass = as_constant(a.smass);
 
-    int32_t v_base = 0, v_lo = 0, v_hi = 0;      // register-lane stack: entry k lives in lane k
+    int32_t v_base = 0, v_lo = 0, v_hi = 0;      // register-lane stack: entry k lives in lane k & 63 of the
+    int32_t v_base2 = 0, v_lo2 = 0, v_hi2 = 0;   // first (k < 64) or second triple: 128 entries (walk_tree_asm)
     int sp = 0;                                   // wave-uniform
 
     auto eval = [&](const float cx, const float cy, const int32_t mbits, const float thr, const int32_t child,
@@ -381,10 +405,14 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
             if (open != 0) {                                // ~30 % of the evaluated nodes
                 if (LDS_STACK) {
                     if (lane == 0) { s_base[w][sp] = child; s_mask[w][sp] = open; }
-                } else {
+                } else if (sp < kWave) {
                     v_base = bh_writelane_i32(child, sp, v_base);
                     v_lo = bh_writelane_i32((int32_t)(uint32_t)open, sp, v_lo);
                     v_hi = bh_writelane_i32((int32_t)(uint32_t)(open >> 32), sp, v_hi);
+                } else {
+                    v_base2 = bh_writelane_i32(child, sp - kWave, v_base2);
+                    v_lo2 = bh_writelane_i32((int32_t)(uint32_t)open, sp - kWave, v_lo2);
+                    v_hi2 = bh_writelane_i32((int32_t)(uint32_t)(open >> 32), sp - kWave, v_hi2);
                 }
                 ++sp;
             }
@@ -419,7 +447,6 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
         }
     };
 
-    bool stack_overflow = false;
     auto pop_raw = [&](int32_t &base, uint64_t &mask) {         // sp > 0
         --sp;
         if (LDS_STACK) {
@@ -427,10 +454,14 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
             const uint64_t m = s_mask[w][sp];
             mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(m >> 32)) << 32) |
                    (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)m);
-        } else {
+        } else if (sp < kWave) {
             base = __builtin_amdgcn_readlane(v_base, sp);
             mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v_hi, sp) << 32) |
                    (uint32_t)__builtin_amdgcn_readlane(v_lo, sp);
+        } else {
+            base = __builtin_amdgcn_readlane(v_base2, sp - kWave);
+            mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v_hi2, sp - kWave) << 32) |
+                   (uint32_t)__builtin_amdgcn_readlane(v_lo2, sp - kWave);
         }
     };
     // take the next quad entry off the stack; bucket references (-(node id) - 2) are served on the
@@ -603,7 +634,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
             if (t >= 0 && t == a.self_rank) continue;
             int32_t base = (t < 0) ? 0 : (int32_t)(a.forest_base + (int64_t)t * a.let_cap);
             if (ASM) {
-                if (walk_tree_asm(quads, aux, cpos, cmass, base, everyone, p.x, p.y, ax, ay)) stack_overflow = true;
+                walk_tree_asm(quads, aux, cpos, cmass, base, everyone, a.pair_limit, p.x, p.y, ax, ay);
                 continue;
             }
             // the C++ statement of walk_tree_asm's loop: same order, same operations
@@ -620,13 +651,10 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
                     continue;
                 }
                 bool two = false;
-                if (sp > 0 && sp <= kPairLimit) {
+                if (sp > 0 && sp <= a.pair_limit) {
                     pop_raw(bB, mB);
                     if (bB < 0) ++sp;                           // a bucket reference: leave it on the stack
                     else two = true;
-                } else if (sp > (LDS_STACK ? kLdsStackDepth - 4 : kSingleLimit)) {
-                    stack_overflow = true;
-                    break;
                 }
                 const QuadRegs A = load_quad(quads + bA);
                 if (two) {
@@ -637,7 +665,6 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
                     eval_quad(A, mA);
                 }
             }
-            if (stack_overflow) break;
         }
     }
 
@@ -686,7 +713,6 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
             }
         }
     } else if (a.partial) block_bounds_to_partial(valid, bx, by, a.partial + 4 * (size_t)lb);
-    if (stack_overflow && lane == 0) a.ctr->walk_overflow = 1;
     if (STATS && lane == 0) {
         atomicAdd(&a.ctr->visits, n_vis);
         atomicAdd(&a.ctr->interactions, n_int);

@@ -64,6 +64,12 @@ class BhStats:
     build_ms: float
     walk_ms: float
     device_bytes: int
+    keys_ms: float = 0.0        # per kernel group of the last timed step
+    sort_ms: float = 0.0
+    scan_ms: float = 0.0
+    nodes_ms: float = 0.0
+    build_bytes: int = 0        # algorithmic bytes of that step
+    walk_bytes: int = 0
 
 
 def _dptr(a: np.ndarray):
@@ -183,7 +189,8 @@ class BarnesHutEngine:
         s = _lib.bh_stats_t()
         self._check(self._lib.bh_stats(self._h, C.byref(s)))
         return BhStats(s.n_bodies, s.n_nodes, s.n_internal, s.steps_done, s.visits, s.interactions,
-                       s.wave_nodes, s.last_step_ms, s.build_ms, s.walk_ms, s.device_bytes)
+                       s.wave_nodes, s.last_step_ms, s.build_ms, s.walk_ms, s.device_bytes, s.keys_ms, s.sort_ms,
+                       s.scan_ms, s.nodes_ms, s.build_bytes, s.walk_bytes)
 
     # -- multi-GPU plumbing -----------------------------------------------------------------
     def set_owned_fraction(self, rank: int, world: int) -> None:

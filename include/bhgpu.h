@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BHGPU_ABI_VERSION 1
+#define BHGPU_ABI_VERSION 2   /* 2: bh_stats_t carries per-kernel-group times and algorithmic bytes */
 
 typedef enum bh_status {
     BH_OK = 0,
@@ -118,6 +118,16 @@ typedef struct bh_stats_t {
     double   build_ms;           /* bounds+keys+sort+nodes+COM of the last timed step       */
     double   walk_ms;            /* walk+integrate kernel of the last timed step            */
     uint64_t device_bytes;       /* device memory held by the context                       */
+    /* per kernel group of the last timed step (HIP events on the context's stream):
+     * the reference times "GPU parallel computation" as a whole (project.cu:957, 1008)          */
+    double   keys_ms;            /* root box + keys (bounds_final, keys_kernel)              */
+    double   sort_ms;            /* radix passes (+ the state re-ordering when it ran)       */
+    double   scan_ms;            /* cell counts, sorted copies, ranks, prefix sums           */
+    double   nodes_ms;           /* node records (+ the bottom-up mass pass in exact mode)   */
+    /* algorithmic bytes of that step: what each kernel must read and write once            */
+    uint64_t build_bytes;        /* keys + sort passes + scan + nodes                        */
+    uint64_t walk_bytes;         /* walk + integrate: 44 B per body + 20 B per node a
+                                    wavefront evaluates (needs BH_FLAG_WALK_STATS, else 0)    */
 } bh_stats_t;
 
 typedef struct bh_ctx bh_ctx;

@@ -2,7 +2,10 @@
 """Condense a gpurun_out/<tag>/ profile directory (scripts/gpu_profile.sh) into profiles/<name>/:
 kernel_stats.csv (rocprofv3 --kernel-trace --stats), pmc_summary.csv (per-kernel counter means) and
 bench.json.  usage: summarize_profile.py gpurun_out/<tag> profiles/<name>"""
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob, json, os, shutil, subprocess, sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from gpu_nbody_simulation_amd.build import source_digest  # noqa: E402
 
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
@@ -27,7 +30,7 @@ with open(f"{dst}/pmc_summary.csv", "w", newline="") as fh:
 # WRITE_SIZE are in KB, collected in separate --pmc passes; on gfx950 FETCH_SIZE reports exactly 1/2
 # of the bytes read -- calibrated for THIS kernel's access pattern (wave-uniform 64-byte scalar
 # loads) with scripts/calib/fetch_calib.hip: ratio 0.50003 -- so reads = 2 * FETCH_SIZE.
-walk = {c: v for (k, c, n, v) in rows if k.startswith("void bh::walk_fast_kernel<false, false")}
+walk = {c: v for (k, c, n, v) in rows if k.startswith("void bh::walk_fast_kernel<false, false, 0, 1")}
 calib = {}
 for f in glob.glob(f"{src}/calib/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
@@ -37,7 +40,10 @@ if "FETCH_SIZE" in walk and "WRITE_SIZE" in walk:
     t = {"kernel": "walk_fast_kernel", "fetch_size_kb": walk["FETCH_SIZE"], "write_size_kb": walk["WRITE_SIZE"],
          "fetch_correction": 2.0, "traffic_bytes": 2.0 * walk["FETCH_SIZE"] * 1024 + walk["WRITE_SIZE"] * 1024,
          "l2_hit_rate": walk.get("TCC_HIT_sum", 0) / max(1.0, walk.get("TCC_HIT_sum", 0) + walk.get("TCC_MISS_sum", 0)),
-         "calibration_fetch_size_over_true_bytes": calib, "source": os.path.basename(dst)}
+         "calibration_fetch_size_over_true_bytes": calib, "source": os.path.basename(dst),
+         # what the profile was measured on: bench.py drops `traffic` when the kernels have changed since
+         "source_digest": source_digest(),
+         "git_head": subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None}
     json.dump(t, open(f"{dst}/walk_traffic.json", "w"), indent=1)
     json.dump(t, open(os.path.join(os.path.dirname(dst.rstrip("/")), "latest_walk_traffic.json"), "w"), indent=1)
     print(json.dumps(t))

@@ -174,15 +174,29 @@ def test_bucket_mode_matches_uncapped_oracle(kind, n, md):
         assert np.median(r) < 1e-2
 
 
-def test_deep_tree_uses_lds_stack():
-    """max_depth > 21 cannot use the 64-entry register-lane stack; the LDS variant takes over."""
-    m, p, v = IC.make("plummer", 16384, 3)
+@pytest.mark.parametrize("flags", [0, FLAG_LDS_STACK, FLAG_WALK_PORTABLE])
+def test_deep_trees_fit_the_stack(flags):
+    """max_depth 32: the 128-entry register-lane stack pairs entries only while sp <= 120 - 3 * 31 = 27, which
+    keeps every wavefront inside its bound (walk_tree_asm); the asm loop, the C++ loop and the LDS-stack
+    variant agree bitwise.  A clumped input makes the tree really deep."""
+    rng = np.random.default_rng(8)
+    n = 16384
+    p = f32(np.concatenate([rng.normal(0, 1e-5, (n // 4, 2)), rng.normal(0, 1e-3, (n // 4, 2)), rng.uniform(-1, 1, (n // 2, 2))]))
+    m, v = f32(rng.uniform(0.1, 0.5, n)), np.zeros((n, 2))
     t = O.build_tree(p, m, 0)
     ref = O.compute_forces(t, p, m, compat_self_skip=False) / m[:, None]
-    with engine(16384, max_depth=32, reference_compat=False) as e:
+    with engine(n, max_depth=32, reference_compat=False, flags=flags | FLAG_WALK_NO_SPLIT) as e:
         e.upload(p, v, m)
         e.compute_forces()
-        check_tolerance(e.accelerations(), ref)
+        a = e.accelerations()
+        nodes, depth = e.export_tree()
+    assert depth.max() >= 23
+    check_tolerance(a, ref)
+    if flags:
+        with engine(n, max_depth=32, reference_compat=False, flags=FLAG_WALK_NO_SPLIT) as e:
+            e.upload(p, v, m)
+            e.compute_forces()
+            assert np.array_equal(a, e.accelerations())
 
 
 def test_coincident_bodies_do_not_poison_the_run():

@@ -1,0 +1,121 @@
+"""BASELINE config 2 as stated: N = 65,536, theta = 0.5, fp32, uniform-random init, 1,000 steps on one
+MI355X -- run for real and with bodies that MOVE (the 1,000 steps had only ever been run by
+scripts/stress.py, and the bench workload is quasi-static).
+
+The workload: the shipped files' uniform distribution with every body drifting ~0.7 depth-12 cell widths
+per step in a random direction and masses light enough that no close encounter ejects anything -- over
+1,000 steps the cloud spreads to several times its size, every body changes its leaf cell hundreds of
+times, the root box grows every step, and the state is physically re-ordered ~60 times (every 16th
+build).  Checked: (i) a 10-step prefix against the oracle (project.cu:575-675 restated, uncapped tree,
+fp64) within the stated one-step / few-step tolerances; (ii) after 1,000 steps the state is finite, no
+body is lost or duplicated (masses come back in caller order), the tree built on the final state is the
+oracle's depth-21 tree of that state, and one more force evaluation meets the fp32 tolerances against the
+oracle on the final (spread-out) state; (iii) the trajectory is reproducible run to run and, being
+ballistic to first order, follows x0 + k*v0 to the accumulated-acceleration level."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bh_oracle as O  # noqa: E402
+import gpu_nbody_simulation_amd as G  # noqa: E402
+from gpu_nbody_simulation_amd import initial_conditions as IC  # noqa: E402
+from gpu_nbody_simulation_amd.engine import FLAG_WALK_STATS  # noqa: E402
+
+N, STEPS = 65536, 1000
+
+
+def rel(a, ref):
+    return np.linalg.norm(a - ref, axis=1) / np.linalg.norm(ref, axis=1)
+
+
+def workload():
+    m, p, v = IC.make("uniform", N, 21, quasi_static=True, drift_cells=0.7)
+    return m, p, v
+
+
+def oracle_steps(m, p, v, k):
+    pos, vel = p.copy(), v.copy()
+    for _ in range(k):
+        t = O.build_tree(pos, m, 0)
+        f = O.compute_forces(t, pos, m, compat_self_skip=False)
+        _, vel, pos = O.integrate(f, m, vel, pos)
+    return pos, vel
+
+
+def test_config2_thousand_dynamic_steps():
+    m, p, v = workload()
+    cfg = G.BhConfig(capacity=N, theta=0.5, max_depth=21, precision=G.Precision.F32, reference_compat=False,
+                     flags=FLAG_WALK_STATS)
+    box = max(np.ptp(p[:, 0]), np.ptp(p[:, 1]))
+    with G.BarnesHutEngine(cfg) as e:
+        e.upload(p, v, m)
+        # ---- (i) 10-step prefix against the oracle.  (The masses are tiny on purpose: the velocity change of a
+        # step, ~1e-14, is far below the fp32 spacing of |v| ~ 4e-5, so in fp32 the motion is ballistic and
+        # the oracle's is to 1e-9 relative; the FORCES of the moving configuration are what is compared.)
+        e.compute_forces()
+        a0 = e.accelerations()
+        f0 = O.compute_forces(O.build_tree(p, m, 0), p, m, compat_self_skip=False)
+        r0 = rel(a0, f0 / m[:, None])
+        assert np.median(r0) <= 2e-6 and np.quantile(r0, 0.999) <= 1e-4 and r0.max() <= 5e-3
+        e.step(10)
+        p10, v10 = e.download()
+        po, vo = oracle_steps(m, p, v, 10)
+        assert np.abs(p10 - po).max() <= 1e-6 * box                     # fp32 positions: 10 roundings of ~7e-9
+        dvel = np.abs(v10 - vo).max(axis=1)                              # (close pairs pick up more than an fp32 ulp of v)
+        assert np.median(dvel) <= 1e-7 * np.abs(v).max() and dvel.max() <= 1e-4 * np.abs(v).max()
+        moved = np.linalg.norm(p10 - p, axis=1)
+        assert np.median(moved) > 5 * 0.7 * 1.2 * box / 4096            # the bodies really drift (10 steps ~ 7 cells)
+        # ---- (ii) the remaining 990 steps in chunks (every chunk end: finite, nothing lost)
+        done = 10
+        while done < STEPS:
+            k = min(330, STEPS - done)
+            e.step(k)
+            done += k
+            pk, vk = e.download()
+            assert np.isfinite(pk).all() and np.isfinite(vk).all()
+        assert e.stats().steps_done == STEPS
+        assert np.array_equal(e.masses(), m)                              # caller order survived ~60 re-orderings
+        pf, vf = pk, vk
+        spread = max(np.ptp(pf[:, 0]), np.ptp(pf[:, 1])) / box
+        assert spread > 1.3                                               # the cloud has grown: the root box moved every step
+        # ballistic to first order: x0 + k v0 up to the accumulated accelerations and fp32 rounding of 1,000 adds
+        drift = np.abs(pf - (p + STEPS * v)).max()
+        assert drift < 2e-3 * box, drift
+        # the tree of the final state is the oracle's, and its forces meet the fp32 tolerances
+        e.compute_forces()
+        a = e.accelerations()
+        st = e.stats()
+    t = O.build_tree(pf, m, 0)
+    f, ws = O.compute_forces(t, pf, m, compat_self_skip=False, with_stats=True)
+    r = rel(a, f / m[:, None])
+    assert np.median(r) <= 2e-6 and np.quantile(r, 0.999) <= 1e-4 and r.max() <= 5e-3, (np.median(r), r.max())
+    assert st.n_nodes == len(O.build_tree(pf, m, 21))
+    assert abs(st.interactions - ws.interactions) <= 2e-4 * ws.interactions
+    # ---- (iii) reproducible
+    with G.BarnesHutEngine(G.BhConfig(capacity=N, theta=0.5, max_depth=21, precision=G.Precision.F32,
+                                      reference_compat=False)) as e:
+        e.upload(p, v, m)
+        e.step(STEPS)
+        p2, v2 = e.download()
+    assert np.array_equal(p2, pf) and np.array_equal(v2, vf)
+
+
+def test_dynamic_workload_churns_the_sorted_order():
+    """What the dynamic bench leg claims: with drift_cells = 1 most bodies change their depth-12 cell and
+    their rank in the sorted order every step (so no timed step sorts an already sorted array), while the
+    step stays correct against the oracle."""
+    import bench
+    n = 1 << 17
+    m, p, v = IC.make("plummer", n, 1, quasi_static=True, drift_cells=1.0)
+    with G.BarnesHutEngine(G.BhConfig(capacity=n, theta=0.5, max_depth=21, precision=G.Precision.F32,
+                                      reference_compat=False)) as e:
+        e.upload(p, v, m)
+        e.step(5)
+        q0, _ = e.download()
+        e.step(1)
+        q1, w1 = e.download()
+    ch = bench.rank_churn(q0, q1)
+    assert ch["cell12_changed_frac"] > 0.5 and ch["rank_changed_frac"] > 0.9, ch
+    po, vo = oracle_steps(m, q0, v, 1)
+    assert np.abs(q1 - po).max() <= 1e-6 * max(np.ptp(q0[:, 0]), np.ptp(q0[:, 1]))
