@@ -48,6 +48,19 @@ class bh_stats_t(C.Structure):
     ]
 
 
+ORB_BINS = 4096
+ORB_MAX_CUTS = 63
+
+
+class bh_orb_cuts(C.Structure):
+    _fields_ = [
+        ("world", C.c_int32), ("n_cuts", C.c_int32),
+        ("box", C.c_double * 4),
+        ("axis", C.c_int32 * ORB_MAX_CUTS), ("pad", C.c_int32),
+        ("value", C.c_double * ORB_MAX_CUTS),
+    ]
+
+
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
 _ctx = C.c_void_p
@@ -90,6 +103,12 @@ SIGNATURES = {
     "bh_let_walk_local": (C.c_int, [_ctx]),
     "bh_let_walk_remote": (C.c_int, [_ctx, C.c_int32]),
     "bh_let_counts": (C.c_int, [_ctx, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
+    "bh_set_ids": (C.c_int, [_ctx, C.POINTER(C.c_int64)]),
+    "bh_get_ids": (C.c_int, [_ctx, C.POINTER(C.c_int64)]),
+    "bh_orb_histogram": (C.c_int, [_ctx, C.POINTER(bh_orb_cuts), C.c_int32, C.POINTER(_vp), C.POINTER(C.c_int64)]),
+    "bh_migrate_pack": (C.c_int, [_ctx, C.POINTER(bh_orb_cuts), C.POINTER(C.c_int64)]),
+    "bh_migrate_pointers": (C.c_int, [_ctx, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int64)]),
+    "bh_migrate_unpack": (C.c_int, [_ctx, C.c_int64]),
 }
 
 _lib = None

@@ -18,6 +18,7 @@
 #include "bh_walk_exact.hpp"
 #include "bh_init.hpp"
 #include "bh_let.hpp"
+#include "bh_migrate.hpp"
 #include "bh_walk_fast.h"
 
 using namespace bh;
@@ -102,6 +103,12 @@ struct bh_ctx {
     double *lbounds = nullptr, *all_bounds = nullptr;
     float2 *acc_part = nullptr;    // LET mode: raw sums of the local-tree walk (bh_let_walk_local)
     LetCounters *let_ctr = nullptr;
+    // migration / re-balancing (bh_migrate.hpp)
+    int64_t *gid = nullptr;             // 64-bit id per body, caller order
+    uint32_t *group_cost = nullptr;     // cost of every 64-body group in the last walk (sorted order)
+    bool group_cost_valid = false;
+    unsigned long long *orb_hist = nullptr;
+    double *mig_send = nullptr, *mig_recv = nullptr;
 
     // measurement
     std::vector<hipEvent_t> ev;        // pairs around the walk kernel, one pair per step
@@ -410,6 +417,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         a.part = part; a.acc_part = c->acc_part;
         a.forest_base = c->forest_base; a.let_cap = c->let_cap;
         a.order_mode = c->walk_order;
+        a.group_cost = (lo == 0 && hi == c->n) ? c->group_cost : nullptr;
         // the register-lane stack holds 128 entries and pairs entries only while the bound of
         // walk_tree_asm allows it, so it serves every max_depth <= 32; the LDS stack is the flag's variant
         const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0;
@@ -432,6 +440,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         if (walk_fast_split_effective(a, lds, mode, split)) per_partial = kWave;
     }
     if (want_partial) c->partial_count = (int)blocks_for(hi - lo, per_partial);
+    if (!c->exact && lo == 0 && hi == c->n) c->group_cost_valid = true;
     return BH_OK;
 }
 
@@ -557,6 +566,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     } else {
         A(&c->qf, c->internal_cap + 1); A(&c->aux, 4 * (c->internal_cap + 1));
         A(&c->cell_first, c->internal_cap + 1);
+        A(&c->gid, cap); A(&c->group_cost, cap / kWave + 2);
         A(&c->coarse, cap / 256 + 2);
         A(&c->spos, cap); A(&c->spos_out, cap + 64 * kBlock + 1024); A(&c->svel, cap + 64 * kBlock + 1024); A(&c->smass, cap);
         A(&c->terms, cap + 1); A(&c->bsum_d3, std::max<size_t>(blocks_for(cap + 1, kTile), blocks_for(std::min<int64_t>(cap, 1 << 22) + 1, kBlock * kSmallItems)) + 8);
@@ -626,6 +636,11 @@ int bh_upload(bh_ctx *c, const double *pos, const double *vel, const double *mas
     c->steps_done = 0;
     c->orig_identity = true;
     c->builds = 0;
+    c->group_cost_valid = false;
+    if (c->gid && n > 0) {
+        hipLaunchKernelGGL(iota_i64_kernel, dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, c->stream, c->gid, n);
+        BH_HIP(c, hipGetLastError());
+    }
     return BH_OK;
 }
 
@@ -682,6 +697,11 @@ int bh_initialize(bh_ctx *c, int64_t n, uint64_t seed, int32_t kind, double lowe
     c->steps_done = 0;
     c->orig_identity = true;
     c->builds = 0;
+    c->group_cost_valid = false;
+    if (c->gid && n > 0) {
+        hipLaunchKernelGGL(iota_i64_kernel, dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, c->stream, c->gid, n);
+        BH_HIP(c, hipGetLastError());
+    }
     return BH_OK;
 }
 
@@ -1217,6 +1237,166 @@ int bh_let_forces(bh_ctx *c)
     if (!c->tree_valid) return fail(c, BH_ERR_STATE, "bh_let_forces before bh_let_build");
     BH_HIP(c, hipSetDevice(c->device));
     return enqueue_walk(c, false, false);
+}
+
+// ---- device-side migration and re-balancing (bh_migrate.hpp) ----------------------------------------
+int bh_set_ids(bh_ctx *c, const int64_t *ids)
+{
+    if (!c || !ids) return fail(c, BH_ERR_ARG, "bh_set_ids: null argument");
+    if (!c->gid) return fail(c, BH_ERR_STATE, "bh_set_ids: fp32 and mixed precision only");
+    if (!c->uploaded) return fail(c, BH_ERR_STATE, "bh_set_ids before bh_upload");
+    BH_HIP(c, hipSetDevice(c->device));
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+    BH_HIP(c, hipMemcpy(c->gid, ids, c->n * sizeof(int64_t), hipMemcpyHostToDevice));
+    return BH_OK;
+}
+
+int bh_get_ids(bh_ctx *c, int64_t *ids)
+{
+    if (!c || !ids) return fail(c, BH_ERR_ARG, "bh_get_ids: null argument");
+    if (!c->gid) return fail(c, BH_ERR_STATE, "bh_get_ids: fp32 and mixed precision only");
+    BH_HIP(c, hipSetDevice(c->device));
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+    BH_HIP(c, hipMemcpy(ids, c->gid, c->n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return BH_OK;
+}
+
+static int check_cuts(bh_ctx *c, const bh_orb_cuts *cuts, const char *who)
+{
+    if (!c || !cuts) return fail(c, BH_ERR_ARG, std::string(who) + ": null argument");
+    if (c->exact) return fail(c, BH_ERR_STATE, std::string(who) + ": fp32 and mixed precision only");
+    if (!c->uploaded) return fail(c, BH_ERR_STATE, std::string(who) + " before bh_upload");
+    if (cuts->world < 1 || cuts->world > kMaxWorld || cuts->n_cuts != cuts->world - 1)
+        return fail(c, BH_ERR_ARG, std::string(who) + ": world must be 1..64 and n_cuts = world - 1");
+    return BH_OK;
+}
+
+int bh_orb_histogram(bh_ctx *c, const bh_orb_cuts *cuts, int32_t level, void **hist, int64_t *n_words)
+{
+    int rc = check_cuts(c, cuts, "bh_orb_histogram");
+    if (rc) return rc;
+    if (!hist || !n_words || level < 0) return fail(c, BH_ERR_ARG, "bh_orb_histogram: bad argument");
+    BH_HIP(c, hipSetDevice(c->device));
+    const size_t words = (size_t)std::max(cuts->n_cuts, 1) * BH_ORB_BINS;
+    if (!c->orb_hist) {
+        rc = dev_alloc(c, &c->orb_hist, (size_t)BH_ORB_MAX_CUTS * BH_ORB_BINS);
+        if (rc) return rc;
+    }
+    BH_HIP(c, hipMemsetAsync(c->orb_hist, 0, words * sizeof(unsigned long long), c->stream));
+    if (c->n > 0) {
+        // weights: the cost of the body's 64-body group in the last full walk; they are indexed by sorted
+        // position, so the bodies are visited through the last build's permutation
+        const bool weighted = c->group_cost_valid && c->tree_valid;
+        const uint32_t *perm = weighted ? c->perm : nullptr;
+        const uint32_t *cost = weighted ? c->group_cost : nullptr;
+        const unsigned g = blocks_for(c->n, kBlock);
+        if (c->state64)
+            hipLaunchKernelGGL((orb_hist_kernel<double2>), dim3(g), dim3(kBlock), 0, c->stream, (const double2 *)c->pos,
+                               perm, cost, c->n, *cuts, (int)level, c->orb_hist);
+        else
+            hipLaunchKernelGGL((orb_hist_kernel<float2>), dim3(g), dim3(kBlock), 0, c->stream, (const float2 *)c->pos,
+                               perm, cost, c->n, *cuts, (int)level, c->orb_hist);
+        BH_HIP(c, hipGetLastError());
+    }
+    *hist = c->orb_hist;
+    *n_words = (int64_t)words;
+    return BH_OK;
+}
+
+static int migrate_buffers(bh_ctx *c)
+{
+    if (c->mig_send) return BH_OK;
+    const size_t cap = (size_t)std::max<int64_t>(c->cfg.capacity, 1) * kMigrateRecord;
+    int rc = dev_alloc(c, &c->mig_send, cap);
+    if (!rc) rc = dev_alloc(c, &c->mig_recv, cap);
+    return rc;
+}
+
+int bh_migrate_pack(bh_ctx *c, const bh_orb_cuts *cuts, int64_t *send_counts)
+{
+    int rc = check_cuts(c, cuts, "bh_migrate_pack");
+    if (rc) return rc;
+    if (!send_counts) return fail(c, BH_ERR_ARG, "bh_migrate_pack: null argument");
+    BH_HIP(c, hipSetDevice(c->device));
+    rc = migrate_buffers(c);
+    if (rc) return rc;
+    const int64_t n = c->n;
+    const int W = cuts->world;
+    for (int r = 0; r < W; ++r) send_counts[r] = 0;
+    c->tree_valid = false;                                  // the sort buffers are reused from here on
+    if (n == 0) { BH_HIP(c, hipStreamSynchronize(c->stream)); return BH_OK; }
+    hipStream_t st = c->stream;
+    const unsigned g = blocks_for(n, kBlock);
+    if (c->state64)
+        hipLaunchKernelGGL((migrate_classify_kernel<double2>), dim3(g), dim3(kBlock), 0, st, (const double2 *)c->pos, n,
+                           *cuts, c->keys[0], c->vals[0]);
+    else
+        hipLaunchKernelGGL((migrate_classify_kernel<float2>), dim3(g), dim3(kBlock), 0, st, (const float2 *)c->pos, n,
+                           *cuts, c->keys[0], c->vals[0]);
+    // one stable radix pass on the destination rank (< 64 < 256): slots grouped by destination, slot order kept
+    const unsigned nbl = blocks_for(n, kSortTile);
+    hipLaunchKernelGGL((radix_hist<kSortItems, kSortBits>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->radix_counts, n,
+                       0, (int)nbl);
+    hipLaunchKernelGGL(radix_rowscan, dim3(1 << kSortBits), dim3(kBlock), 0, st, c->radix_counts, c->bsum_sort, (int)nbl);
+    hipLaunchKernelGGL((radix_scatter_w<kSortItems, kSortBits>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->vals[0],
+                       c->keys[1], c->vals[1], c->radix_counts, c->bsum_sort, n, 0, (int)nbl);
+    const uint32_t *orig = c->orig_identity ? nullptr : c->orig;
+    if (c->state64)
+        hipLaunchKernelGGL((migrate_pack_kernel<double2, double>), dim3(g), dim3(kBlock), 0, st, c->vals[1],
+                           (const double2 *)c->pos, (const double2 *)c->vel, (const double *)c->mass, orig, c->gid, n,
+                           c->mig_send);
+    else
+        hipLaunchKernelGGL((migrate_pack_kernel<float2, float>), dim3(g), dim3(kBlock), 0, st, c->vals[1],
+                           (const float2 *)c->pos, (const float2 *)c->vel, (const float *)c->mass, orig, c->gid, n,
+                           c->mig_send);
+    BH_HIP(c, hipGetLastError());
+    uint32_t totals[kMaxWorld];
+    BH_HIP(c, hipMemcpyAsync(totals, c->bsum_sort, W * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    BH_HIP(c, hipStreamSynchronize(st));
+    int64_t sum = 0;
+    for (int r = 0; r < W; ++r) { send_counts[r] = totals[r]; sum += totals[r]; }
+    if (sum != n) return fail(c, BH_ERR_DEVICE, "bh_migrate_pack: destination counts do not add up");
+    return BH_OK;
+}
+
+int bh_migrate_pointers(bh_ctx *c, void **send, void **recv, int64_t *capacity_records)
+{
+    if (!c) return BH_ERR_ARG;
+    if (c->exact) return fail(c, BH_ERR_STATE, "bh_migrate_pointers: fp32 and mixed precision only");
+    BH_HIP(c, hipSetDevice(c->device));
+    int rc = migrate_buffers(c);
+    if (rc) return rc;
+    if (send) *send = c->mig_send;
+    if (recv) *recv = c->mig_recv;
+    if (capacity_records) *capacity_records = std::max<int64_t>(c->cfg.capacity, 1);
+    return BH_OK;
+}
+
+int bh_migrate_unpack(bh_ctx *c, int64_t n_new)
+{
+    if (!c) return BH_ERR_ARG;
+    if (c->exact || !c->mig_recv) return fail(c, BH_ERR_STATE, "bh_migrate_unpack before bh_migrate_pack");
+    if (n_new < 0 || n_new > c->cfg.capacity)
+        return fail(c, BH_ERR_CAPACITY, "bh_migrate_unpack: " + std::to_string(n_new) + " bodies arrive, capacity is " +
+                                        std::to_string(c->cfg.capacity));
+    BH_HIP(c, hipSetDevice(c->device));
+    if (n_new > 0) {
+        const unsigned g = blocks_for(n_new, kBlock);
+        if (c->state64)
+            hipLaunchKernelGGL((migrate_unpack_kernel<double2, double>), dim3(g), dim3(kBlock), 0, c->stream, c->mig_recv,
+                               n_new, (double2 *)c->pos, (double2 *)c->vel, (double *)c->mass, (float2 *)c->force, c->gid);
+        else
+            hipLaunchKernelGGL((migrate_unpack_kernel<float2, float>), dim3(g), dim3(kBlock), 0, c->stream, c->mig_recv,
+                               n_new, (float2 *)c->pos, (float2 *)c->vel, (float *)c->mass, (float2 *)c->force, c->gid);
+        BH_HIP(c, hipGetLastError());
+    }
+    c->n = n_new;
+    c->partial_count = 0;
+    c->tree_valid = false;
+    c->orig_identity = true;                                // arrival order is the caller order from here on
+    c->builds = 0;
+    c->group_cost_valid = false;
+    return BH_OK;
 }
 
 int bh_let_counts(bh_ctx *c, uint32_t *counts, int32_t *overflow)

@@ -241,11 +241,13 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
 // taken, four at the last); a pair iteration is entered with at most pair_limit + 1 entries and leaves at
 // most pair_limit + 7.  With pair_limit = 120 - 3 * Dm (60 at max_depth 21, 27 at max_depth 32) the stack
 // never exceeds 128 entries whatever the tree -- the engine passes it in (0 = never pair).
-__device__ __forceinline__ void walk_tree_asm(const QuadF BH_CONSTANT *quads, const NodeAux BH_CONSTANT *aux,
-                                              const float2 BH_CONSTANT *cpos, const float BH_CONSTANT *cmass,
-                                              int32_t root, uint64_t everyone, int32_t pair_limit, float px,
-                                              float py, float &ax, float &ay)
+// returns the number of loop iterations (the cost of this group's walk of this tree)
+__device__ __forceinline__ uint32_t walk_tree_asm(const QuadF BH_CONSTANT *quads, const NodeAux BH_CONSTANT *aux,
+                                                  const float2 BH_CONSTANT *cpos, const float BH_CONSTANT *cmass,
+                                                  int32_t root, uint64_t everyone, int32_t pair_limit, float px,
+                                                  float py, float &ax, float &ay)
 {
+    uint32_t cost;
     asm volatile(
         "s_mov_b64 s[62:63], exec\n"
         "v_mov_b32_e32 v20, %[px]\n"
@@ -256,9 +258,11 @@ __device__ __forceinline__ void walk_tree_asm(const QuadF BH_CONSTANT *quads, co
         "s_mov_b32 s60, %[root]\n"
         "s_mov_b64 s[56:57], %[every]\n"
         "s_mov_b32 s88, 0\n"
+        "s_mov_b32 %[cost], 1\n"                                // loop iterations: the group's cost (re-balancing weight)
         "s_branch LloadAF_%=\n"                                 // the root quad alone
         // ---------------------------------------------------------------- next entries
         "Lloop_%=:\n"
+        "s_add_u32 %[cost], %[cost], 1\n"
         "s_cmp_gt_u32 m0, 56\n"
         "s_cbranch_scc1 LloopChk_%=\n"
         BH_ITERATION("F", BH_POP_FAST("s60", "s56", "s57"), BH_POP_FAST("s86", "s84", "s85"), BH_NOCHK)
@@ -307,7 +311,7 @@ __device__ __forceinline__ void walk_tree_asm(const QuadF BH_CONSTANT *quads, co
         "s_mov_b64 exec, s[62:63]\n"
         "v_mov_b32_e32 %[ax], v28\n"
         "v_mov_b32_e32 %[ay], v29\n"
-        : [ax] "+v"(ax), [ay] "+v"(ay)
+        : [ax] "+v"(ax), [ay] "+v"(ay), [cost] "=&s"(cost)
         : [quads] "s"(quads), [aux] "s"(aux), [cpos] "s"(cpos), [cmass] "s"(cmass), [root] "s"(root),
           [every] "s"(everyone), [px] "v"(px), [py] "v"(py), [plim] "s"(pair_limit)
         : "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
@@ -315,6 +319,7 @@ __device__ __forceinline__ void walk_tree_asm(const QuadF BH_CONSTANT *quads, co
           "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",
           "s84", "s85", "s86", "s87", "s88", "m0", "vcc", "scc", "memory",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35");
+    return cost;
 }
 #undef BH_CHILD
 #undef BH_ITERATION
@@ -366,6 +371,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
     if (a.part == 2 && valid && (SPLIT == 1 || w == 0)) { const float2 t = a.acc_part[s]; ax = t.x; ay = t.y; }
     asm volatile("" : "+v"(ax), "+v"(ay));                // (same for this load: no s_waitcnt vmcnt in the loop)
     unsigned long long n_vis = 0, n_int = 0, n_wave = 0;
+    uint32_t cost = 0;                                       // loop iterations of this group's walk (re-balancing weight)
 
     const QuadF BH_CONSTANT *quads = as_constant(a.quads);
     const NodeAux BH_CONSTANT *aux = as_constant(a.aux);
@@ -510,6 +516,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
         };
         int cur = 0;
         while (F > 0) {                                         // one iteration per tree level
+            cost += (uint32_t)F;
             int produced = 0;
             for (int r0 = 0; r0 < F; r0 += SPLIT * kSplitRound) {
                 const int rem = (F - r0 < SPLIT * kSplitRound) ? F - r0 : SPLIT * kSplitRound;
@@ -634,15 +641,17 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
             if (t >= 0 && t == a.self_rank) continue;
             int32_t base = (t < 0) ? 0 : (int32_t)(a.forest_base + (int64_t)t * a.let_cap);
             if (ASM) {
-                walk_tree_asm(quads, aux, cpos, cmass, base, everyone, a.pair_limit, p.x, p.y, ax, ay);
+                cost += walk_tree_asm(quads, aux, cpos, cmass, base, everyone, a.pair_limit, p.x, p.y, ax, ay);
                 continue;
             }
             // the C++ statement of walk_tree_asm's loop: same order, same operations
             {
                 const QuadRegs q = load_quad(quads + base);
                 eval_quad(q, everyone);
+                ++cost;
             }
             while (sp > 0) {
+                ++cost;
                 int32_t bA, bB = 0;
                 uint64_t mA, mB = 0;
                 pop_raw(bA, mA);
@@ -713,6 +722,11 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
             }
         }
     } else if (a.partial) block_bounds_to_partial(valid, bx, by, a.partial + 4 * (size_t)lb);
+    if (a.group_cost && lane == 0 && (SPLIT == 1 || w == 0)) {
+        const int64_t g = (SPLIT > 1 ? a.lo + (int64_t)lb * kWave : a.lo + (int64_t)lb * kBlock + (int64_t)w * kWave) >> 6;
+        if (a.part == 2) a.group_cost[g] += cost;               // the second launch of a split forest walk adds its share
+        else a.group_cost[g] = cost;
+    }
     if (STATS && lane == 0) {
         atomicAdd(&a.ctr->visits, n_vis);
         atomicAdd(&a.ctr->interactions, n_int);

@@ -275,5 +275,53 @@ class BarnesHutEngine:
         self._check(self._lib.bh_let_counts(self._h, arr, None))
         return list(arr)
 
+    # -- device-side migration and re-balancing (LET scheme) ------------------------------------
+    def set_ids(self, ids) -> None:
+        a = np.ascontiguousarray(ids, dtype=np.int64).reshape(-1)
+        if len(a) != self.n:
+            raise ValueError("one id per body")
+        self._check(self._lib.bh_set_ids(self._h, a.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    def ids(self) -> np.ndarray:
+        a = np.empty(self.n, dtype=np.int64)
+        self._check(self._lib.bh_get_ids(self._h, a.ctypes.data_as(C.POINTER(C.c_int64))))
+        return a
+
+    @staticmethod
+    def _cuts_struct(cuts):
+        c = _lib.bh_orb_cuts()
+        c.world, c.n_cuts = cuts.world, cuts.world - 1
+        for k in range(4):
+            c.box[k] = float(cuts.box[k])
+        for k in range(cuts.world - 1):
+            c.axis[k], c.value[k] = int(cuts.axis[k]), float(cuts.value[k])
+        return c
+
+    def orb_histogram(self, cuts, level: int):
+        """(device pointer, number of uint64 words) of the weighted histograms of the cut tree's regions
+        at `level` (row k = the region whose cut is k, ORB_BINS bins across the root box)."""
+        c = self._cuts_struct(cuts)
+        p, nw = C.c_void_p(), C.c_int64()
+        self._check(self._lib.bh_orb_histogram(self._h, C.byref(c), level, C.byref(p), C.byref(nw)))
+        return p.value, nw.value
+
+    def migrate_pack(self, cuts):
+        """Classify the local bodies by the cut tree and group them by destination in the send buffer;
+        returns the number of bodies for every rank (waits for the stream)."""
+        c = self._cuts_struct(cuts)
+        cnt = (C.c_int64 * cuts.world)()
+        self._check(self._lib.bh_migrate_pack(self._h, C.byref(c), cnt))
+        return list(cnt)
+
+    def migrate_pointers(self):
+        """(send, recv device pointers, capacity in records of 6 doubles)."""
+        s, r, cap = C.c_void_p(), C.c_void_p(), C.c_int64()
+        self._check(self._lib.bh_migrate_pointers(self._h, C.byref(s), C.byref(r), C.byref(cap)))
+        return s.value, r.value, cap.value
+
+    def migrate_unpack(self, n_new: int) -> None:
+        self._check(self._lib.bh_migrate_unpack(self._h, n_new))
+        self.n = n_new
+
     def set_stream(self, hip_stream: int) -> None:
         self._check(self._lib.bh_set_stream(self._h, C.c_void_p(hip_stream)))

@@ -256,6 +256,42 @@ int bh_let_forces(bh_ctx *ctx);
 int bh_let_walk_local(bh_ctx *ctx);
 int bh_let_walk_remote(bh_ctx *ctx, int32_t integrate);
 int bh_let_counts(bh_ctx *ctx, uint32_t *counts, int32_t *overflow);
+/* --- device-side body migration and re-balancing for the LET scheme -------
+ * The reference is single-GPU (project.cu:918-1024 keeps every body on one device); this is new design.
+ * Ownership is defined by an orthogonal-recursive-bisection cut tree over the global root box: the node
+ * that splits the ranks [r0, r0 + nr) (nr > 1) into nl = nr / 2 and nr - nl sends a body with
+ * coordinate[axis] < value to the left.  Cuts are stored in pre-order: the left subtree's cuts follow
+ * their parent directly (nl - 1 of them), the right subtree's come after those.
+ *   bh_orb_histogram : for every region of depth `level` of the cut tree (cuts above it already fixed),
+ *                      a histogram of this rank's bodies over BH_ORB_BINS bins across the ROOT box along
+ *                      the region's axis (bin edges = depth-12 lines of the tree grid, so a cut taken
+ *                      from it is a grid line), each body weighted by the cost of its 64-body group in the
+ *                      last walk (1 before the first walk).  *hist = device pointer to n_cuts x
+ *                      BH_ORB_BINS uint64 (row k = the region whose cut is k): the caller all-reduces it.
+ *   bh_migrate_pack  : classify every local body by the cut tree, group the bodies by destination rank
+ *                      (stable) into the send buffer -- 6 doubles per body: x, y, vx, vy, mass, id -- and
+ *                      return the W counts (host; waits for the stream).
+ *   [host: all_to_all of the counts, then ONE all_to_all of the records on the device pointers of
+ *    bh_migrate_pointers with those splits; a rank's own group travels with the rest]
+ *   bh_migrate_unpack: the received records become the local state (n_new bodies, arrival order =
+ *                      caller order from here on); the tree is invalid until the next build.
+ * bh_set_ids / bh_get_ids: a 64-bit identifier per body in caller order (default: the upload index);
+ * it travels with the body. */
+#define BH_ORB_BINS 4096
+#define BH_ORB_MAX_CUTS 63
+typedef struct bh_orb_cuts {
+    int32_t world, n_cuts;           /* n_cuts = world - 1                                       */
+    double  box[4];                  /* global root box: xmin, xmax, ymin, ymax                  */
+    int32_t axis[BH_ORB_MAX_CUTS];   /* 0 = x, 1 = y                                             */
+    int32_t pad;
+    double  value[BH_ORB_MAX_CUTS];
+} bh_orb_cuts;
+int bh_set_ids(bh_ctx *ctx, const int64_t *ids);
+int bh_get_ids(bh_ctx *ctx, int64_t *ids);
+int bh_orb_histogram(bh_ctx *ctx, const bh_orb_cuts *cuts, int32_t level, void **hist, int64_t *n_words);
+int bh_migrate_pack(bh_ctx *ctx, const bh_orb_cuts *cuts, int64_t *send_counts);
+int bh_migrate_pointers(bh_ctx *ctx, void **send, void **recv, int64_t *capacity_records);
+int bh_migrate_unpack(bh_ctx *ctx, int64_t n_new);
 /* Run on an external HIP stream (e.g. torch's current stream), passed as void*. */
 int bh_set_stream(bh_ctx *ctx, void *hip_stream);
 

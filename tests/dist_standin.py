@@ -102,12 +102,50 @@ class LetStandInEngine:
         self.vel = np.array(vel, dtype=np.float32).reshape(-1, 2)
         self.mass = np.array(mass, dtype=np.float32).reshape(-1)
         self.n = len(self.mass)
+        self.gid = np.arange(self.n, dtype=np.int64)
+        if not hasattr(self, "capacity"):
+            self.capacity = 4 * self.n + 64                   # head-room for migration, as a real context would have
 
     def download(self):
         return self.pos.astype(np.float64), self.vel.astype(np.float64)
 
     def masses(self):
         return self.mass.astype(np.float64)
+
+    # ---- migration surface (bh_set_ids ... bh_migrate_unpack), numpy twins of csrc/bh_migrate.hpp
+    def set_ids(self, ids):
+        self.gid = np.array(ids, dtype=np.int64).reshape(-1)
+        assert len(self.gid) == self.n
+
+    def ids(self):
+        return self.gid.copy()
+
+    def sync(self):
+        pass
+
+    def orb_histogram(self, cuts, level):
+        return torch.from_numpy(cuts.histogram(self.pos.astype(np.float64), np.ones(self.n), level).reshape(-1).copy())
+
+    def migrate_pointers(self):
+        if not hasattr(self, "_mig"):
+            self._mig = (torch.zeros(6 * self.capacity, dtype=torch.float64), torch.zeros(6 * self.capacity, dtype=torch.float64))
+        return self._mig[0], self._mig[1], self.capacity
+
+    def migrate_pack(self, cuts):
+        own = cuts.owner(self.pos.astype(np.float64))
+        order = np.argsort(own, kind="stable")                # grouped by destination, slot order kept
+        rec = np.concatenate([self.pos, self.vel, self.mass[:, None], self.gid[:, None].astype(np.float64)], axis=1)
+        send = self.migrate_pointers()[0]
+        send[: 6 * self.n] = torch.from_numpy(rec[order].astype(np.float64).reshape(-1))
+        return [int((own == r).sum()) for r in range(cuts.world)]
+
+    def migrate_unpack(self, n_new):
+        rec = self.migrate_pointers()[1][: 6 * n_new].numpy().reshape(n_new, 6)
+        self.pos = rec[:, 0:2].astype(np.float32)
+        self.vel = rec[:, 2:4].astype(np.float32)
+        self.mass = rec[:, 4].astype(np.float32)
+        self.gid = rec[:, 5].astype(np.int64)
+        self.n = n_new
 
     def let_local_quads(self):
         if not hasattr(self, "_lq"):

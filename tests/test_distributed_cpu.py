@@ -112,10 +112,13 @@ def _let_worker(rank, world, port, n, steps, out_dir):
     for k in range(steps):
         st.step()
         if k == 0:
-            # re-deal the bodies after the first step with the other partition: the trajectory must
-            # not notice who owns what
-            st.repartition(lambda pp, w: partition_hilbert(pp, w, align=16)[::-1])
+            # re-deal the bodies after the first step (ORB cuts from the distributed histogram, bodies moved
+            # by all_to_all): the trajectory must not notice who owns what
+            held = st.rebalance()
             cap = st.let_cap
+            assert held == eng.n and st.cuts is not None
+            own = st.cuts.owner(eng.download()[0])
+            assert (own == rank).all()                     # every body sits on the rank the cut tree names
     largest = st.check()
     st.run(0)
     pos, vel = eng.download()
@@ -164,6 +167,93 @@ def test_let_stepper_ranks_reproduce_the_direct_sum(tmp_path, world, n):
     np.testing.assert_allclose(got_v, vel.astype(np.float64), rtol=2e-5, atol=1e-9)
     np.testing.assert_allclose(got_p, pos.astype(np.float64), rtol=2e-6, atol=1e-9)
     assert not np.array_equal(got_p, p64)
+
+
+def _rebalance_worker(rank, world, port, n, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_standin import LetStandInEngine
+    from gpu_nbody_simulation_amd.distributed import LetStepper
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, p, v = _inputs(n)
+    mine = np.arange(rank, n, world)                       # every rank generated "its share": no spatial meaning at all
+    eng = LetStandInEngine()
+    eng.upload(p[mine], v[mine], m[mine])
+    st = LetStepper(eng, rank, world, let_cap=4096, device=torch.device("cpu"), ids=mine)
+    held = [st.rebalance()]
+    st.step()
+    held.append(st.rebalance())                             # a second time on the moved bodies
+    pos, vel = eng.download()
+    np.savez(os.path.join(out_dir, f"reb{rank}.npz"), pos=pos, vel=vel, idx=st.ids, mass=eng.masses(), held=held,
+             axis=st.cuts.axis, value=st.cuts.value, box=st.cuts.box)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rebalance_deals_arbitrary_shares_into_balanced_orb_domains(tmp_path, world):
+    """no rank ever holds all bodies.  Every rank starts with an arbitrary share (every
+    world-th body); rebalance() derives the ORB cuts from the all-reduced histograms and moves the bodies by
+    all_to_all: afterwards every body is on the rank its position selects, nobody is lost or duplicated,
+    ids, masses and velocities travelled with their bodies, all ranks hold the same cut tree, the shares are
+    balanced, and the trajectory is the single-process one."""
+    n = 600
+    port = _free_port()
+    mp.spawn(_rebalance_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
+    from oracle import bh_oracle as O
+    from gpu_nbody_simulation_amd.distributed import OrbCuts
+    m, p, v = _inputs(n)
+    m64 = m.astype(np.float64)
+    a = O.direct_forces(p.astype(np.float64), m64) / m64[:, None]
+    vel = v + a.astype(np.float32)
+    pos = p + vel
+    d = [np.load(tmp_path / f"reb{r}.npz") for r in range(world)]
+    idx = np.concatenate([x["idx"] for x in d])
+    assert np.array_equal(np.sort(idx), np.arange(n))       # conserved: every id exactly once
+    got_p = np.concatenate([x["pos"] for x in d])
+    got_v = np.concatenate([x["vel"] for x in d])
+    got_m = np.concatenate([x["mass"] for x in d])
+    np.testing.assert_array_equal(got_m, m64[idx])          # masses followed their ids
+    np.testing.assert_allclose(got_v, vel.astype(np.float64)[idx], rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(got_p, pos.astype(np.float64)[idx], rtol=2e-6, atol=1e-9)
+    for r in range(1, world):                               # one cut tree everywhere
+        assert np.array_equal(d[r]["axis"], d[0]["axis"]) and np.array_equal(d[r]["value"], d[0]["value"])
+    cuts = OrbCuts(world, d[0]["box"])
+    cuts.axis[:], cuts.value[:] = d[0]["axis"], d[0]["value"]
+    for r in range(world):
+        assert (cuts.owner(d[r]["pos"]) == r).all()         # ownership = the cut tree
+        assert abs(len(d[r]["idx"]) - n / world) <= 0.08 * n / world + 2, [len(x["idx"]) for x in d]
+        assert list(d[r]["held"]) [-1] == len(d[r]["idx"])
+
+
+def test_orb_cut_tree_numpy_twin():
+    """OrbCuts.descend / histogram / choose_cut: pre-order cut layout for any world size, histograms add up,
+    the chosen cut is a tree-grid line that balances the two sides."""
+    from gpu_nbody_simulation_amd.distributed import ORB_BINS, OrbCuts, choose_cut, padded_root_box
+    rng = np.random.default_rng(1)
+    p = np.concatenate([rng.normal(0, 0.02, (15000, 2)), rng.uniform(-0.2, 0.2, (5000, 2))])
+    w = rng.integers(1, 50, len(p))
+    for world in (1, 2, 3, 6, 8):
+        c = OrbCuts(world, padded_root_box(p[:, 0].min(), p[:, 0].max(), p[:, 1].min(), p[:, 1].max()))
+        for level in range(c.depth()):
+            regs = c.regions(level)
+            for k, _, _, rb in regs:
+                c.axis[k] = int((rb[3] - rb[2]) > (rb[1] - rb[0]))
+            h = c.histogram(p, w, level)
+            r0, kk, nr = c.descend(p, level)
+            assert h.sum() == w[nr > 1].sum()
+            for k, r_first, nr_k, rb in regs:
+                val = choose_cut(h[k], rb, c.box, int(c.axis[k]), (nr_k // 2) / nr_k)
+                c.value[k] = val
+                ax = int(c.axis[k])
+                e = (val - c.box[2 * ax]) / (c.box[2 * ax + 1] - c.box[2 * ax]) * ORB_BINS
+                assert abs(e - round(e)) < 1e-6 and rb[2 * ax] < val < rb[2 * ax + 1]   # a grid line inside the region
+        own = c.owner(p)
+        assert own.min() >= 0 and own.max() == world - 1
+        share = np.array([w[own == r].sum() for r in range(world)]) / w.sum()
+        assert np.abs(share - 1.0 / world).max() <= 0.06 / world + 0.01, share          # weighted balance
 
 
 def test_partition_orb_is_a_balanced_partition_into_disjoint_boxes():

@@ -18,11 +18,12 @@ pytestmark = pytest.mark.gpu
 from oracle import bh_oracle as O  # noqa: E402
 import gpu_nbody_simulation_amd as G  # noqa: E402
 from gpu_nbody_simulation_amd import initial_conditions as IC  # noqa: E402
-from gpu_nbody_simulation_amd.distributed import partition_hilbert, partition_orb, wrap_device  # noqa: E402
+from gpu_nbody_simulation_amd.distributed import (ORB_BINS, OrbCuts, choose_cut, padded_root_box,  # noqa: E402
+                                                  partition_hilbert, partition_orb, wrap_device)
 
 
 class EmulatedRanks:
-    def __init__(self, mass, pos, vel, world, let_cap, partition=partition_orb, **cfg):
+    def __init__(self, mass, pos, vel, world, let_cap, partition=partition_orb, headroom=1.0, **cfg):
         self.world = world
         self.parts = partition(pos, world)
         dev = torch.device("cuda", 0)
@@ -31,15 +32,68 @@ class EmulatedRanks:
         # every context sized for ITS OWN bodies, as bench.py does: the contexts' quad arrays then differ
         # in size, and only the agreed forest_base makes a sender's links land in the receiver's blocks
         for ix in self.parts:
-            e = G.BarnesHutEngine(G.BhConfig(capacity=max(len(ix), 1), **cfg))
+            e = G.BarnesHutEngine(G.BhConfig(capacity=max(int(headroom * len(ix)), 1), **cfg))
+            e.set_stream(torch.cuda.current_stream().cuda_stream)   # one stream for the contexts and the "collectives"
             e.upload(pos[ix], vel[ix], mass[ix])
+            e.set_ids(ix)
             self.engs.append(e)
         self.forest_base = max(e.let_local_quads() for e in self.engs)
+        self.dev = dev
+        self.configure(let_cap)
+
+    def configure(self, let_cap):
+        self.let_cap, self.bufs = let_cap, []
+        dev, world = self.dev, self.world
         for r, e in enumerate(self.engs):
             e.let_configure(r, world, let_cap, self.forest_base)
             lb, ab, sd, rv, nb, k = e.let_pointers()
             self.bufs.append((wrap_device(lb, 4 * k, "<f8", dev), wrap_device(ab, 4 * k * world, "<f8", dev),
                               wrap_device(sd, world * nb, "|u1", dev), wrap_device(rv, world * nb, "|u1", dev), nb))
+
+    def rebalance(self, tol=0.01):
+        """LetStepper.rebalance() with the three collectives replaced by device copies / sums between the
+        contexts of this one GPU: the device code (histogram, classify, group, pack, unpack) is the real one.
+        Returns (cuts, summed histograms per level)."""
+        W, dev = self.world, self.dev
+        for e in self.engs:
+            e.let_bounds()
+        torch.cuda.synchronize()
+        b = torch.cat([x[0] for x in self.bufs]).cpu().numpy().reshape(-1, 4)
+        b = b[np.isfinite(b).all(1) & (b[:, 0] <= b[:, 1])]
+        cuts = OrbCuts(W, padded_root_box(b[:, 0].min(), b[:, 1].max(), b[:, 2].min(), b[:, 3].max()))
+        hists = []
+        for level in range(cuts.depth()):
+            regs = cuts.regions(level)
+            for k, _, _, rb in regs:
+                cuts.axis[k] = int((rb[3] - rb[2]) > (rb[1] - rb[0]))
+            tot = None
+            for e in self.engs:
+                ptr, nw = e.orb_histogram(cuts, level)
+                h = wrap_device(ptr, nw, "<i8", dev).clone()
+                tot = h if tot is None else tot + h                      # "all_reduce"
+            hh = tot.cpu().numpy().reshape(-1, ORB_BINS)
+            hists.append(hh)
+            for k, _, nr, rb in regs:
+                cuts.value[k] = choose_cut(hh[k], rb, cuts.box, int(cuts.axis[k]), (nr // 2) / nr, tol)
+        counts = [e.migrate_pack(cuts) for e in self.engs]               # counts[src][dst]
+        ptrs = [e.migrate_pointers() for e in self.engs]
+        send = [wrap_device(p[0], p[2] * 6, "<f8", dev) for p in ptrs]
+        recv = [wrap_device(p[1], p[2] * 6, "<f8", dev) for p in ptrs]
+        for dst in range(W):                                             # "all_to_all_single" with splits
+            o = 0
+            for src in range(W):
+                c = counts[src][dst]
+                so = sum(counts[src][:dst])
+                assert o + c <= ptrs[dst][2], "capacity"
+                recv[dst][6 * o: 6 * (o + c)].copy_(send[src][6 * so: 6 * (so + c)])
+                o += c
+            self.engs[dst].migrate_unpack(o)
+        torch.cuda.synchronize()
+        self.cuts = cuts
+        return cuts, hists
+
+    def ids(self):
+        return [e.ids() for e in self.engs]
 
     def step(self, integrate=True, two_launches=False):
         for e in self.engs:
@@ -67,10 +121,10 @@ class EmulatedRanks:
             e.sync()
 
     def gather(self, what):
-        n = sum(len(ix) for ix in self.parts)
+        n = sum(e.n for e in self.engs)
         out = np.zeros((n, 2))
-        for e, ix in zip(self.engs, self.parts):
-            out[ix] = what(e)
+        for e in self.engs:
+            out[e.ids()] = what(e)                                       # ids = the caller's global indices
         return out
 
     def close(self):
@@ -249,6 +303,88 @@ def test_local_tree_overflow_is_reported_through_the_let_counters():
         engs[0].sync()                                           # and bh_sync names the cause
     for e in engs:
         e.close()
+
+
+def test_device_migration_matches_the_numpy_twin():
+    """bh_orb_histogram / bh_migrate_pack / bh_migrate_unpack against OrbCuts (the numpy statement of the
+    same rules): integer histograms equal bin for bin, every body ends on the rank the cut tree names, in
+    (source rank, slot) order, and x, v, m and the id of every body arrive bit for bit."""
+    n, W = 60000, 3
+    m, p, v = IC.make("uniform", n, 13)
+    v = (v + 1e-5).astype(np.float32).astype(np.float64)
+    er = EmulatedRanks(m, p, v, W, let_cap=8192, partition=lambda pp, w: [np.arange(r, n, w) for r in range(w)],
+                       headroom=3.0, max_depth=21, reference_compat=False)
+    cuts, hists = er.rebalance()
+    ref = OrbCuts(W, cuts.box)
+    for level, hh in enumerate(hists):                                    # same cut decisions from the same integers
+        for k, _, _, rb in ref.regions(level):
+            ref.axis[k] = int((rb[3] - rb[2]) > (rb[1] - rb[0]))
+        h = ref.histogram(p, np.ones(n), level)
+        assert np.array_equal(h, hh)
+        for k, _, nr, rb in ref.regions(level):
+            ref.value[k] = choose_cut(h[k], rb, ref.box, int(ref.axis[k]), (nr // 2) / nr)
+    assert np.array_equal(ref.axis, cuts.axis) and np.array_equal(ref.value, cuts.value)
+    own = ref.owner(p)
+    seen = np.zeros(n, dtype=int)
+    for r, e in enumerate(er.engs):
+        ids = e.ids()
+        seen[ids] += 1
+        assert (own[ids] == r).all()
+        # arrival order: grouped by source rank (bodies r::W came from rank r), each group in slot order
+        src = ids % W
+        assert (np.diff(src) >= 0).all() and all((np.diff(ids[src == q]) > 0).all() for q in range(W))
+        pos, vel = e.download()
+        assert np.array_equal(pos, p[ids]) and np.array_equal(vel, v[ids]) and np.array_equal(e.masses(), m[ids])
+        assert abs(e.n - n / W) <= 0.05 * n / W
+    assert (seen == 1).all()
+    er.configure(8192)
+    er.step(integrate=False)                                              # and the forest still is the direct sum's equal
+    a = er.gather(lambda e: e.accelerations())
+    er.close()
+    with G.BarnesHutEngine(G.BhConfig(capacity=n, precision=G.Precision.F32, max_depth=21, reference_compat=False)) as e:
+        e.upload(p, v, m)
+        e.compute_forces()
+        a1 = e.accelerations()
+    assert np.median(rel(a, a1)) < 2e-3
+
+
+def test_drifting_cloud_stays_balanced_over_200_steps():
+    """a distribution that drifts across the cuts.  A uniform cloud moves one cloud width
+    to the right in 200 steps (plus random motion); the bodies are re-dealt on the device every 10 steps with
+    cuts weighted by the last walk's per-group cost.  After every re-deal the shares are within 10 % of n/W,
+    the largest LET stays within 12 % of its mean over the twenty re-deals, no body is lost, and the final state is the ballistic one
+    (the masses are tiny) whoever owned the body on the way."""
+    n, W, steps, every = 120000, 4, 200, 10
+    m, p, v = IC.make("uniform", n, 17, quasi_static=True)
+    rng = np.random.default_rng(2)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    v = (v + np.stack([1e-3 + 3e-4 * np.cos(ang), 3e-4 * np.sin(ang)], 1)).astype(np.float32).astype(np.float64)
+    er = EmulatedRanks(m, p, v, W, let_cap=16384, headroom=1.6, max_depth=21, reference_compat=False)
+    shares, lets, moved = [], [], 0
+    for s in range(steps):
+        er.step()
+        if (s + 1) % every == 0:
+            before = [set(ix.tolist()) for ix in er.ids()]
+            er.rebalance()
+            after = er.ids()
+            moved += sum(len(set(ix.tolist()) - b) for ix, b in zip(after, before))
+            er.configure(er.let_cap)
+            er.step(integrate=False)
+            shares.append([e.n for e in er.engs])
+            lets.append(max(max(e.let_counts()) for e in er.engs))
+    shares = np.array(shares)
+    assert np.abs(shares / (n / W) - 1.0).max() <= 0.10, shares
+    # (at step 0 the cloud is centred in its root box and the median IS the coarsest grid line -- a special
+    # case; what must hold is that the LETs neither grow as the cloud moves on nor come near their blocks)
+    lets = np.array(lets, dtype=float)
+    assert np.abs(lets / lets.mean() - 1.0).max() <= 0.12 and lets.max() < 0.25 * er.let_cap, lets
+    assert moved > 0.5 * n                                                # bodies really changed hands: > half of them in all
+    ids = np.concatenate(er.ids())
+    assert np.array_equal(np.sort(ids), np.arange(n))
+    pf = er.gather(lambda e: e.download()[0])
+    er.close()
+    # (fp32 positions: 200 additions of ~1e-3 round at ~1.5e-8 each)
+    assert np.abs(pf - (p + steps * v)).max() < 1e-5
 
 
 def test_ranks_without_bodies():
