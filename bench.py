@@ -192,27 +192,37 @@ def main():
     prec = G.Precision.MIXED if a.precision == "mixed" else G.Precision.F32
     if prec == G.Precision.MIXED and a.decomposition == "replicated" and (a.gpus > 1 or a.force_sharded):
         raise SystemExit("bench.py: --precision mixed runs on one GPU or with --decomposition let")
-    mass, pos, vel = IC.make(a.init, n, a.seed, quasi_static=True)
     flags = FLAG_LDS_STACK if a.lds_stack else 0
-    cfg = G.BhConfig(capacity=n, theta=a.theta, max_depth=a.max_depth, precision=prec,
-                     reference_compat=False, device=local, flags=flags)
     sharded = world > 1 or a.force_sharded
     use_let = sharded and a.decomposition == "let"
     let_info = None
     if use_let:
-        # every rank derives the same partition from the same synthetic state and keeps its part only
-        mine = partition_orb(pos, world)[rank]
-        cfg = G.BhConfig(capacity=max(len(mine), 1), theta=a.theta, max_depth=a.max_depth,
+        # LET decomposition: NO rank ever generates or holds all bodies.  Every rank draws its own share of the
+        # chunk-wise defined state (IC.make_share), then the bodies are dealt into ORB domains on the devices
+        # (LetStepper.rebalance: distributed histograms, one all_to_all of records) -- twice: by count before
+        # the first walk, by the measured per-group cost after a few steps.
+        lo_i, hi_i = n * rank // world, n * (rank + 1) // world
+        mass, pos, vel = IC.make_share(a.init, n, a.seed, lo_i, hi_i, quasi_static=True)
+        cfg = G.BhConfig(capacity=int(1.5 * n / world) + 4096, theta=a.theta, max_depth=a.max_depth,
                          precision=prec, reference_compat=False, device=local, flags=flags)
-    eng = G.BarnesHutEngine(cfg)
-    if sharded:
-        eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    if use_let:
-        eng.upload(pos[mine], vel[mine], mass[mine])  # this rank's bodies, resident in HBM from here on
+        eng = G.BarnesHutEngine(cfg)
+        eng.upload(pos, vel, mass)                    # this rank's share, resident in HBM from here on
         overlap = a.let_overlap == "on" or (a.let_overlap == "auto" and world >= 4)
-        stepper = LetStepper(eng, rank, world, let_cap=1 << 14, device=dev, overlap=overlap)
-        cap = stepper.autotune()                      # block size from the measured LET sizes (untimed)
+        stepper = LetStepper(eng, rank, world, let_cap=1 << 14, device=dev, overlap=overlap,
+                             ids=np.arange(lo_i, hi_i, dtype=np.int64))
+        stepper.rebalance()
+        for _ in range(3):
+            stepper.step()
+        stepper.rebalance()                           # cost-weighted; also re-sizes the LET blocks (autotune)
+        cap = stepper.let_cap
+        bodies_here = eng.n
     else:
+        mass, pos, vel = IC.make(a.init, n, a.seed, quasi_static=True)
+        cfg = G.BhConfig(capacity=n, theta=a.theta, max_depth=a.max_depth, precision=prec,
+                         reference_compat=False, device=local, flags=flags)
+        eng = G.BarnesHutEngine(cfg)
+        if sharded:
+            eng.set_stream(torch.cuda.current_stream().cuda_stream)
         eng.upload(pos, vel, mass)                    # bodies resident in HBM from here on
         stepper = ShardedStepper(eng, rank, world, n, dev, force_exchange=a.force_sharded)
 
@@ -241,40 +251,49 @@ def main():
         largest = stepper.check()                    # raises if a LET outgrew its block: run invalid
         let_info = {"let_cap_quads": cap, "largest_let_quads": largest,
                     "all_to_all_bytes_per_rank_per_step": cap * 80 * (world - 1),
-                    "bodies_on_rank0": int(len(mine))}
+                    "bodies_on_rank0": int(bodies_here), "bodies_per_rank_balanced": n / world}
 
     st = eng.stats()                                 # HIP events recorded inside the timed region
     walk_ms = st.walk_ms if not sharded else None
 
     # ---- untimed: counters of one walk on the final state (second engine, stats variant) --------
-    pf, vf = eng.download()
+    ss = None
     if use_let:
-        # the final state lives in pieces: collect it on every rank for the untimed stats walk
-        pieces = [None] * world
+        # distributed, like the run itself: every rank walks ITS final bodies once more with the counting
+        # kernels (own tree + LETs of the others); the counters and Newton's third law are all-reduced
+        pf, vf = eng.download()
+        mf, idf = eng.masses(), eng.ids()
+        se = G.BarnesHutEngine(G.BhConfig(capacity=max(len(mf), 1), theta=a.theta, max_depth=a.max_depth, precision=prec,
+                                          reference_compat=False, device=local, flags=flags | FLAG_WALK_STATS))
+        se.upload(pf, vf, mf)
+        sst = LetStepper(se, rank, world, let_cap=cap, device=dev, ids=idf)
+        sst.step(integrate=False)
+        sst.check()
+        s1 = se.stats()
+        acc = se.accelerations()
+        red = torch.tensor([float(s1.interactions), float(s1.wave_nodes), float(s1.n_nodes),
+                            *(mf[:, None] * acc).sum(0), (mf[:, None] * np.abs(acc)).sum()], dtype=torch.float64)
         if world > 1:
-            dist.all_gather_object(pieces, (mine, pf, vf))
-        else:
-            pieces = [(mine, pf, vf)]
-        pf, vf = np.empty((n, 2)), np.empty((n, 2))
-        for ix, pp, vv in pieces:
-            pf[ix], vf[ix] = pp, vv
+            red = red.to(dev) if a.backend == "nccl" else red
+            dist.all_reduce(red)
+            red = red.cpu()
+        let_info["net_force_over_sum_abs_force"] = float(max(abs(red[3]), abs(red[4])) / max(float(red[5]), 1e-300))
+        se.close()
+
+        class _S:                                    # the fields the report below reads
+            interactions, wave_nodes, n_nodes = int(red[0]), int(red[1]), int(red[2])
+        ss = _S
+    else:
+        pf, vf = eng.download()
     out = None
     if rank == 0:
-        with G.BarnesHutEngine(G.BhConfig(capacity=n, theta=a.theta, max_depth=a.max_depth,
-                                          precision=prec, reference_compat=False, device=local,
-                                          flags=flags | FLAG_WALK_STATS)) as se:
-            se.upload(pf, vf, mass)
-            se.compute_forces()
-            ss = se.stats()
-            if use_let:
-                # sanity of the distributed forces: rank 0's accelerations of the last step against a
-                # single tree over the gathered state (partial cells differ at the 1e-3 level; a broken
-                # exchange would differ at O(1))
-                a_one, a_let = se.accelerations()[mine], eng.accelerations()
-                nrm = np.linalg.norm(a_one, axis=1)
-                ok = nrm > 0
-                let_info["accel_median_rel_diff_vs_single_tree"] = float(
-                    np.median(np.linalg.norm(a_let - a_one, axis=1)[ok] / nrm[ok])) if ok.any() else 0.0
+        if ss is None:
+            with G.BarnesHutEngine(G.BhConfig(capacity=n, theta=a.theta, max_depth=a.max_depth,
+                                              precision=prec, reference_compat=False, device=local,
+                                              flags=flags | FLAG_WALK_STATS)) as se:
+                se.upload(pf, vf, mass)
+                se.compute_forces()
+                ss = se.stats()
         u64 = ss.wave_nodes / n                      # distinct nodes per body per 64-body group
         # algorithmic bytes of ONE walk+integrate launch (DESIGN.md "Roofline"):
         #   per body: sorted pos 8 + perm 4 + vel r/w 16 + pos w 8 + accel w 8 = 44 B
@@ -313,7 +332,7 @@ def main():
             "config": {"workload": f"{a.init}_N{n}_theta{a.theta}", "n_bodies": n, "theta": a.theta,
                        "max_depth": a.max_depth, "init": a.init, "seed": a.seed,
                        "parallelism": "1 GPU" if not sharded else
-                       (f"orb x{world}, local trees + LET all_to_all/step" + (" (overlapped)" if overlap else "") if use_let
+                       (f"orb x{world} (cuts from distributed histograms, bodies dealt on the devices), local trees + LET all_to_all/step" + (" (overlapped)" if overlap else "") if use_let
                         else f"replicated build, hilbert-range walk x{world}, all_gather/step")},
             "minteractions_per_s": ss.interactions * a.steps / elapsed / 1e6,
             "interactions_per_body": ss.interactions / n,

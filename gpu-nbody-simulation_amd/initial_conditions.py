@@ -105,3 +105,29 @@ def make(kind: str, n: int, seed: int = 1, quasi_static: bool = False, drift_cel
         ang = r.uniform(0.0, 2.0 * np.pi, size=n)
         v = _f32(v + drift_cells * cell * np.stack([np.cos(ang), np.sin(ang)], axis=1))
     return m, p, v
+
+
+SHARE_CHUNK = 65536
+
+
+def make_share(kind: str, n: int, seed: int, lo: int, hi: int, quasi_static: bool = True):
+    """Bodies [lo, hi) of an n-body synthetic state that is defined chunk by chunk (SHARE_CHUNK bodies per
+    chunk, chunk c drawn from its own counter-based stream), so that ANY rank can generate exactly its own
+    share without generating -- or ever holding -- the rest: the multi-GPU benchmark's input (every rank
+    calls this with its own range; the union over ranks is the same state for every world size).  Same
+    distributions and mass scale as make(); not the same bodies as make(kind, n, seed), whose Plummer
+    rejection sampling consumes its stream sequentially."""
+    if not (0 <= lo <= hi <= n):
+        raise ValueError("make_share: need 0 <= lo <= hi <= n")
+    ms, ps, vs = [], [], []
+    for c in range(lo // SHARE_CHUNK, (max(hi, lo + 1) - 1) // SHARE_CHUNK + 1):
+        c0 = c * SHARE_CHUNK
+        cn = min(SHARE_CHUNK, n - c0)
+        if cn <= 0:
+            break
+        m, p, v = make(kind, cn, seed * 1000003 + c + 1, quasi_static=quasi_static)
+        a, b = max(lo, c0) - c0, min(hi, c0 + cn) - c0
+        ms.append(m[a:b]); ps.append(p[a:b]); vs.append(v[a:b])
+    if not ms:
+        return np.zeros(0), np.zeros((0, 2)), np.zeros((0, 2))
+    return np.concatenate(ms), np.concatenate(ps), np.concatenate(vs)

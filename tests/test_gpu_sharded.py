@@ -120,13 +120,19 @@ def test_bench_let_path_with_three_ranks_sharing_the_gpu(tmp_path):
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 3 and d["config"]["parallelism"].startswith("orb x3")
     assert 0 < d["let"]["largest_let_quads"] <= d["let"]["let_cap_quads"]
-    # the forces the ranks computed from each other's trees are the single-tree forces (ranks hold
-    # different numbers of bodies, so their quad arrays differ in size: the agreed forest_base matters)
-    assert d["let"]["accel_median_rel_diff_vs_single_tree"] < 5e-3
-    assert 20000 < d["let"]["bodies_on_rank0"] < 24000
-    # the state gathered from the three ranks after 4 steps is the state one GPU reaches
-    assert abs(d["n_nodes"] - one["n_nodes"]) <= 0.001 * one["n_nodes"]
-    assert abs(d["interactions_per_body"] - one["interactions_per_body"]) <= 1e-3 * one["interactions_per_body"]
+    # No rank ever holds all bodies (every rank draws its share, the bodies are dealt on the devices), so the
+    # checks are distributed too: the forces the ranks computed from each other's trees obey Newton's third
+    # law to the multipole error (a broken exchange would leave O(1)), the shares are balanced, and the work
+    # per body is that of the same state walked as ONE rank's forest (world size 1 through the same path).
+    assert d["let"]["net_force_over_sum_abs_force"] < 2e-3
+    assert abs(d["let"]["bodies_on_rank0"] - 65536 / 3) < 0.15 * 65536 / 3
+    r0 = subprocess.run([sys.executable] + base + ["--force-sharded"], capture_output=True, text=True, timeout=600, env=env)
+    assert r0.returncode == 0, r0.stderr[-2000:]
+    one_let = json.loads([l for l in r0.stdout.splitlines() if l.startswith("{")][-1])
+    assert one_let["config"]["parallelism"].startswith("orb x1")
+    # (a cell that straddles two ranks becomes two partial cells, each accepted on its own: the forest does a
+    # little MORE work per body than one tree -- +10 % at this small size on 3 ranks -- never less)
+    assert 1.0 <= d["interactions_per_body"] / one_let["interactions_per_body"] <= 1.15
     # the replicated decomposition through the same rehearsal path (the box allows 6 processes on the
     # GPU, this test process included, so world sizes stay at 3-4)
     for extra, world in ((["--decomposition", "replicated"], 3), ([], 4)):
@@ -137,7 +143,11 @@ def test_bench_let_path_with_three_ranks_sharing_the_gpu(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert d["n_gpus"] == world
-        assert abs(d["n_nodes"] - one["n_nodes"]) <= 0.001 * one["n_nodes"]
-        assert abs(d["interactions_per_body"] - one["interactions_per_body"]) <= 1e-3 * one["interactions_per_body"]
-        if not extra:
-            assert d["let"]["accel_median_rel_diff_vs_single_tree"] < 5e-3
+        if extra:                                           # replicated tree: the same bodies, the same tree as one GPU
+            assert abs(d["n_nodes"] - one["n_nodes"]) <= 0.001 * one["n_nodes"]
+            assert abs(d["interactions_per_body"] - one["interactions_per_body"]) <= 1e-3 * one["interactions_per_body"]
+        else:
+            assert d["let"]["net_force_over_sum_abs_force"] < 2e-3
+            # (a cell that straddles two ranks becomes two partial cells, each accepted on its own: the forest does a
+    # little MORE work per body than one tree -- +10 % at this small size on 3 ranks -- never less)
+    assert 1.0 <= d["interactions_per_body"] / one_let["interactions_per_body"] <= 1.15

@@ -42,3 +42,16 @@ def test_drift_moves_every_body_by_the_stated_number_of_cells():
     assert np.allclose(np.hypot(v[:, 0], v[:, 1]), cell, rtol=1e-5)
     m0, p0, v0 = IC.make("plummer", 8192, 1, quasi_static=True)
     assert np.array_equal(p, p0) and np.array_equal(m, m0)
+
+
+def test_make_share_is_the_same_state_for_every_partition():
+    n = 3 * IC.SHARE_CHUNK // 2 + 17
+    whole = IC.make_share("plummer", n, 4, 0, n)
+    assert len(whole[0]) == n and (whole[0].astype(np.float32) > 1e-15).all()
+    for world in (2, 3):
+        parts = [IC.make_share("plummer", n, 4, n * r // world, n * (r + 1) // world) for r in range(world)]
+        for k in range(3):
+            assert np.array_equal(np.concatenate([q[k] for q in parts]), whole[k])
+    r = np.hypot(whole[1][:, 0], whole[1][:, 1])
+    assert 0.49 < (r < 0.02).mean() < 0.53                   # still a Plummer sphere
+    assert len(IC.make_share("uniform", 100, 1, 40, 40)[0]) == 0
