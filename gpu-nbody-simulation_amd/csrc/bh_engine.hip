@@ -106,9 +106,13 @@ struct bh_ctx {
     // migration / re-balancing (bh_migrate.hpp)
     int64_t *gid = nullptr;             // 64-bit id per body, caller order
     uint32_t *group_cost = nullptr;     // cost of every 64-body group in the last walk (sorted order)
+    const void **walk_consts = nullptr; // device block {aux, spos, smass, 0} for the assembly walk's bucket path
     bool group_cost_valid = false;
     unsigned long long *orb_hist = nullptr;
     double *mig_send = nullptr, *mig_recv = nullptr;
+#ifdef BHGPU_EXPERIMENTS
+    uint64_t *timeline = nullptr;       // BH_WALK_TIMELINE=path: per-wave timestamps of the last walk, dumped by bh_destroy
+#endif
 
     // measurement
     std::vector<hipEvent_t> ev;        // pairs around the walk kernel, one pair per step
@@ -417,7 +421,11 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         a.part = part; a.acc_part = c->acc_part;
         a.forest_base = c->forest_base; a.let_cap = c->let_cap;
         a.order_mode = c->walk_order;
+#ifdef BHGPU_EXPERIMENTS
+        a.timeline = c->timeline;
+#endif
         a.group_cost = (lo == 0 && hi == c->n) ? c->group_cost : nullptr;
+        a.bucket_consts = c->walk_consts;
         // the register-lane stack holds 128 entries and pairs entries only while the bound of
         // walk_tree_asm allows it, so it serves every max_depth <= 32; the LDS stack is the flag's variant
         const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0;
@@ -566,13 +574,24 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     } else {
         A(&c->qf, c->internal_cap + 1); A(&c->aux, 4 * (c->internal_cap + 1));
         A(&c->cell_first, c->internal_cap + 1);
-        A(&c->gid, cap); A(&c->group_cost, cap / kWave + 2);
+        A(&c->gid, cap); A(&c->group_cost, cap / kWave + 2); A(&c->walk_consts, 4);
         A(&c->coarse, cap / 256 + 2);
         A(&c->spos, cap); A(&c->spos_out, cap + 64 * kBlock + 1024); A(&c->svel, cap + 64 * kBlock + 1024); A(&c->smass, cap);
         A(&c->terms, cap + 1); A(&c->bsum_d3, std::max<size_t>(blocks_for(cap + 1, kTile), blocks_for(std::min<int64_t>(cap, 1 << 22) + 1, kBlock * kSmallItems)) + 8);
     }
     if (rc) return bail(rc);
     if (hipMemset(c->ctr, 0, sizeof(TreeCounters)) != hipSuccess) { c->err = "hipMemset failed"; return bail(BH_ERR_DEVICE); }
+    if (!c->exact) {
+        const void *wc[4] = {c->aux, c->spos, c->smass, nullptr};
+        if (hipMemcpy(c->walk_consts, wc, sizeof(wc), hipMemcpyHostToDevice) != hipSuccess) { c->err = "hipMemcpy failed"; return bail(BH_ERR_DEVICE); }
+    }
+#ifdef BHGPU_EXPERIMENTS
+    if (std::getenv("BH_WALK_TIMELINE") && !c->exact) {
+        rc = dev_alloc(c, &c->timeline, 4 * (size_t)(cap / kWave + 8));
+        if (rc) return bail(rc);
+        (void)hipMemset(c->timeline, 0, 4 * (size_t)(cap / kWave + 8) * sizeof(uint64_t));
+    }
+#endif
 #ifdef BHGPU_EXPERIMENTS
     if (hipMemset(c->os_err, 0, 16) != hipSuccess) { c->err = "hipMemset failed"; return bail(BH_ERR_DEVICE); }
 #endif
@@ -588,6 +607,15 @@ void bh_destroy(bh_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+#ifdef BHGPU_EXPERIMENTS
+    if (c->timeline) {
+        const size_t words = 4 * (size_t)((c->n + kWave - 1) / kWave);
+        std::vector<uint64_t> h(words);
+        if (hipMemcpy(h.data(), c->timeline, words * sizeof(uint64_t), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *fp = std::fopen(std::getenv("BH_WALK_TIMELINE"), "wb")) { std::fwrite(h.data(), 8, words, fp); std::fclose(fp); }
+        }
+    }
+#endif
     for (void *p : c->allocs) (void)hipFree(p);
     for (auto e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev_step) if (e) (void)hipEventDestroy(e);

@@ -29,9 +29,11 @@ struct WalkFastArgs {
     float G, dt;
     int integrate, to_sorted;
     uint32_t nblocks, xcd_chunk;   // filled by the launcher
+    const void *bucket_consts;     // device block {aux, spos, smass, 0}: the assembly loop's bucket path reads its pointers here
     uint32_t *group_cost;          // per 64-body group: loop iterations of its walk (load-balancing weight), may be null
     int32_t pair_limit;            // one-wave walk: two stack entries per iteration while sp <= pair_limit
                                    // (120 - 3 * (max_depth - 1), never negative: the 128-entry stack bound)
+    uint64_t *timeline;            // experiments: per-wave {start, end, hw id, cost}
     int32_t order_mode;            // experiment (BH_WALK_ORDER): 0 = blocks in sorted order, 1 = reversed, 2 = strided
     // forest walk (distributed step): besides the local tree (root quad 0) the bodies walk the
     // locally-essential trees received from the peers, whose root quads sit at

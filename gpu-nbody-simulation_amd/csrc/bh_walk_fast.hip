@@ -95,8 +95,10 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
 // the consumer of v_rsq_f32 (trans) is separated from it by the scalar push logic; the consumer of
 // v_pk_add_f32 (packed) by the empty-cell test; m0 is written at least one instruction before a lane
 // select uses it.
-// Fixed SGPRs: s[36:55] quad record, s[56:57] lane mask, s[58:59] open mask / scratch, s60 quad index,
-// s61 byte offset, s[62:63] EXEC on entry.
+// Fixed SGPRs: s[24:43] quad A, s[44:45] its lane mask, s[46:47] B's mask, s[48:67] quad B, s68 / s69 A's quad
+// index and byte offset and, once its loads are issued, the open-mask scratch pair, s70 B's index, s71 B's
+// offset and then the flag "B is in flight".  (The block sits right above the ~24 SGPRs the compiler keeps
+// live across the loop.)
 // Fixed VGPRs (the two-dword operands of v_pk_add_f32 need named halves): v[20:21] body position,
 // v[22:23] dx,dy, v24 d2 then w, v25 1/d, v26 scratch, v[28:29] acceleration sums, v30..v32 the stack.
 #ifndef BH_ASM_EXECZ
@@ -129,7 +131,7 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
 #define BH_PAD_V ""
 #endif
 #if BH_ASM_PAD_SALU
-#define BH_PAD_S "s_mov_b32 s35, s35\n s_mov_b32 s35, s35\n s_mov_b32 s35, s35\n s_mov_b32 s35, s35\n"
+#define BH_PAD_S "s_mov_b32 s70, s70\n s_mov_b32 s70, s70\n s_mov_b32 s70, s70\n s_mov_b32 s70, s70\n"
 #else
 #define BH_PAD_S ""
 #endif
@@ -143,14 +145,14 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
     "v_fmac_f32_e32 v24, v22, v22\n"                                                                \
     "v_cmpx_lt_f32_e32 vcc, " TS ", v24\n"                                                          \
     BH_FORCE_RSQ_EARLY                                                                              \
-    "s_andn2_b64 s[58:59], " MASK ", vcc\n"                                                         \
+    "s_andn2_b64 s[68:69], " MASK ", vcc\n"                                                         \
     "s_cbranch_scc0 Lforce" TAG "_%=\n"                                                             \
     "s_cmp_eq_u32 " CS ", -1\n"                                                                     \
     "s_cbranch_scc1 Lforce" TAG "_%=\n"                                                             \
     PUSHCHK                                                                                         \
     "v_writelane_b32 v30, " CS ", m0\n"                                                             \
-    "v_writelane_b32 v31, s58, m0\n"                                                                \
-    "v_writelane_b32 v32, s59, m0\n"                                                                \
+    "v_writelane_b32 v31, s68, m0\n"                                                                \
+    "v_writelane_b32 v32, s69, m0\n"                                                                \
     "LpushBack" TAG "_%=:\n"                                                                        \
     "s_add_u32 m0, m0, 1\n"                                                                         \
     "Lforce" TAG "_%=:\n"                                                                           \
@@ -169,8 +171,8 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
 #define BH_PUSH_HI(CS, TAG)                                                                         \
     "LpushHi" TAG "_%=:\n"                                                                          \
     "v_writelane_b32 v33, " CS ", m0\n"                                                             \
-    "v_writelane_b32 v34, s58, m0\n"                                                                \
-    "v_writelane_b32 v35, s59, m0\n"                                                                \
+    "v_writelane_b32 v34, s68, m0\n"                                                                \
+    "v_writelane_b32 v35, s69, m0\n"                                                                \
     "s_branch LpushBack" TAG "_%=\n"
 // pop: EXEC = the entry's lane, v_readfirstlane (4.1 cycles each; v_readlane: 8.3)
 #define BH_POP_FAST(IDX, LO, HI)                                                                    \
@@ -191,38 +193,37 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
     "s_sub_u32 m0, m0, 1\n"                              /* SCC = borrow: the stack was empty */    \
     "s_cbranch_scc1 Ldone_%=\n"                                                                     \
     POPA                                                                                            \
-    "s_cmp_lt_i32 s60, 0\n"                                                                         \
+    "s_cmp_lt_i32 s68, 0\n"                                                                         \
     "s_cbranch_scc1 Lspecial_%=\n"                                                                  \
-    "s_mov_b32 s88, 0\n"                                 /* s88: a second quad (B) is in flight */  \
+    "s_mov_b32 s71, 0\n"                                 /* s71 != 0: a second quad (B) is in flight */ \
     "s_cmp_eq_u32 m0, 0\n"                                                                          \
     "s_cbranch_scc1 LloadA" SFX "_%=\n"                                                             \
     "s_cmp_gt_u32 m0, %[plim]\n"                         /* pairs only while the stack bound allows */ \
     "s_cbranch_scc1 LloadA" SFX "_%=\n"                                                             \
     "s_sub_u32 m0, m0, 1\n"                                                                         \
     POPB                                                                                            \
-    "s_cmp_lt_i32 s86, 0\n"                                                                         \
+    "s_cmp_lt_i32 s70, 0\n"                                                                         \
     "s_cbranch_scc1 Lunpop" SFX "_%=\n"                                                             \
-    "s_mov_b32 s88, 1\n"                                                                            \
-    "s_mul_i32 s87, s86, 0x50\n"                                                                    \
-    "s_load_dwordx16 s[64:79], %[quads], s87\n"                                                     \
-    "s_load_dwordx4 s[80:83], %[quads], s87 offset:0x40\n"                                          \
-    "LloadA" SFX "_%=:\n"                                /* s60 = quad index >= 0, s[56:57] = mask */ \
-    "s_mul_i32 s61, s60, 0x50\n"                                                                    \
-    "s_load_dwordx16 s[36:51], %[quads], s61\n"                                                     \
-    "s_load_dwordx4 s[52:55], %[quads], s61 offset:0x40\n"                                          \
-    "s_mov_b64 exec, s[56:57]\n"                                                                    \
+    "s_mul_i32 s71, s70, 0x50\n"                         /* (a quad index >= 1: the offset is not 0) */ \
+    "s_load_dwordx16 s[48:63], %[quads], s71\n"                                                     \
+    "s_load_dwordx4 s[64:67], %[quads], s71 offset:0x40\n"                                          \
+    "LloadA" SFX "_%=:\n"                                /* s68 = quad index >= 0, s[44:45] = mask */ \
+    "s_mul_i32 s69, s68, 0x50\n"                                                                    \
+    "s_load_dwordx16 s[24:39], %[quads], s69\n"                                                     \
+    "s_load_dwordx4 s[40:43], %[quads], s69 offset:0x40\n"                                          \
+    "s_mov_b64 exec, s[44:45]\n"                                                                    \
     "s_waitcnt lgkmcnt(0)\n"                                                                        \
-    BH_CHILD("s[36:37]", "s44", "s48", "s52", "s[56:57]", SFX "A0", CHK(SFX "A0"))                  \
-    BH_CHILD("s[38:39]", "s45", "s49", "s53", "s[56:57]", SFX "A1", CHK(SFX "A1"))                  \
-    BH_CHILD("s[40:41]", "s46", "s50", "s54", "s[56:57]", SFX "A2", CHK(SFX "A2"))                  \
-    BH_CHILD("s[42:43]", "s47", "s51", "s55", "s[56:57]", SFX "A3", CHK(SFX "A3"))                  \
-    "s_cmp_eq_u32 s88, 0\n"                                                                         \
+    BH_CHILD("s[24:25]", "s32", "s36", "s40", "s[44:45]", SFX "A0", CHK(SFX "A0"))                  \
+    BH_CHILD("s[26:27]", "s33", "s37", "s41", "s[44:45]", SFX "A1", CHK(SFX "A1"))                  \
+    BH_CHILD("s[28:29]", "s34", "s38", "s42", "s[44:45]", SFX "A2", CHK(SFX "A2"))                  \
+    BH_CHILD("s[30:31]", "s35", "s39", "s43", "s[44:45]", SFX "A3", CHK(SFX "A3"))                  \
+    "s_cmp_eq_u32 s71, 0\n"                                                                         \
     "s_cbranch_scc1 Lloop_%=\n"                                                                     \
-    "s_mov_b64 exec, s[84:85]\n"                                                                    \
-    BH_CHILD("s[64:65]", "s72", "s76", "s80", "s[84:85]", SFX "B0", CHK(SFX "B0"))                  \
-    BH_CHILD("s[66:67]", "s73", "s77", "s81", "s[84:85]", SFX "B1", CHK(SFX "B1"))                  \
-    BH_CHILD("s[68:69]", "s74", "s78", "s82", "s[84:85]", SFX "B2", CHK(SFX "B2"))                  \
-    BH_CHILD("s[70:71]", "s75", "s79", "s83", "s[84:85]", SFX "B3", CHK(SFX "B3"))                  \
+    "s_mov_b64 exec, s[46:47]\n"                                                                    \
+    BH_CHILD("s[48:49]", "s56", "s60", "s64", "s[46:47]", SFX "B0", CHK(SFX "B0"))                  \
+    BH_CHILD("s[50:51]", "s57", "s61", "s65", "s[46:47]", SFX "B1", CHK(SFX "B1"))                  \
+    BH_CHILD("s[52:53]", "s58", "s62", "s66", "s[46:47]", SFX "B2", CHK(SFX "B2"))                  \
+    BH_CHILD("s[54:55]", "s59", "s63", "s67", "s[46:47]", SFX "B3", CHK(SFX "B3"))                  \
     "s_branch Lloop_%=\n"                                                                           \
     "Lunpop" SFX "_%=:\n"                                /* B is a bucket reference: leave it there */ \
     "s_add_u32 m0, m0, 1\n"                                                                         \
@@ -242,22 +243,21 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
 // most pair_limit + 7.  With pair_limit = 120 - 3 * Dm (60 at max_depth 21, 27 at max_depth 32) the stack
 // never exceeds 128 entries whatever the tree -- the engine passes it in (0 = never pair).
 // returns the number of loop iterations (the cost of this group's walk of this tree)
-__device__ __forceinline__ uint32_t walk_tree_asm(const QuadF BH_CONSTANT *quads, const NodeAux BH_CONSTANT *aux,
-                                                  const float2 BH_CONSTANT *cpos, const float BH_CONSTANT *cmass,
+// consts: device block {aux, sorted positions, sorted masses} -- three pointers only the bucket path needs,
+// kept out of the SGPR budget (the kernel must stay at or below 80 SGPRs for 8 resident waves per SIMD:
+// the allocation is the count + 16, rounded up to 16, out of 800 per SIMD)
+__device__ __forceinline__ uint32_t walk_tree_asm(const QuadF BH_CONSTANT *quads, const void BH_CONSTANT *consts,
                                                   int32_t root, uint64_t everyone, int32_t pair_limit, float px,
                                                   float py, float &ax, float &ay)
 {
     uint32_t cost;
     asm volatile(
-        "s_mov_b64 s[62:63], exec\n"
         "v_mov_b32_e32 v20, %[px]\n"
         "v_mov_b32_e32 v21, %[py]\n"
         "v_mov_b32_e32 v28, %[ax]\n"
         "v_mov_b32_e32 v29, %[ay]\n"
-        "s_mov_b32 m0, 0\n"
-        "s_mov_b32 s60, %[root]\n"
-        "s_mov_b64 s[56:57], %[every]\n"
-        "s_mov_b32 s88, 0\n"
+        "s_mov_b32 m0, 0\n"                                     // (s68 = root quad, s[44:45] = lane mask: bound operands)
+        "s_mov_b32 s71, 0\n"
         "s_mov_b32 %[cost], 1\n"                                // loop iterations: the group's cost (re-balancing weight)
         "s_branch LloadAF_%=\n"                                 // the root quad alone
         // ---------------------------------------------------------------- next entries
@@ -265,59 +265,60 @@ __device__ __forceinline__ uint32_t walk_tree_asm(const QuadF BH_CONSTANT *quads
         "s_add_u32 %[cost], %[cost], 1\n"
         "s_cmp_gt_u32 m0, 56\n"
         "s_cbranch_scc1 LloopChk_%=\n"
-        BH_ITERATION("F", BH_POP_FAST("s60", "s56", "s57"), BH_POP_FAST("s86", "s84", "s85"), BH_NOCHK)
+        BH_ITERATION("F", BH_POP_FAST("s68", "s44", "s45"), BH_POP_FAST("s70", "s46", "s47"), BH_NOCHK)
         "LloopChk_%=:\n"                                        // more than 56 entries: pushes / pops pick their VGPRs
-        BH_ITERATION("C", BH_POP("s60", "s56", "s57", "A"), BH_POP("s86", "s84", "s85", "B"), BH_PUSHCHK)
-        BH_PUSH_HI("s52", "CA0") BH_PUSH_HI("s53", "CA1") BH_PUSH_HI("s54", "CA2") BH_PUSH_HI("s55", "CA3")
-        BH_PUSH_HI("s80", "CB0") BH_PUSH_HI("s81", "CB1") BH_PUSH_HI("s82", "CB2") BH_PUSH_HI("s83", "CB3")
-        BH_POP_HI("s60", "s56", "s57", "A")
-        BH_POP_HI("s86", "s84", "s85", "B")
+        BH_ITERATION("C", BH_POP("s68", "s44", "s45", "A"), BH_POP("s70", "s46", "s47", "B"), BH_PUSHCHK)
+        BH_PUSH_HI("s40", "CA0") BH_PUSH_HI("s41", "CA1") BH_PUSH_HI("s42", "CA2") BH_PUSH_HI("s43", "CA3")
+        BH_PUSH_HI("s64", "CB0") BH_PUSH_HI("s65", "CB1") BH_PUSH_HI("s66", "CB2") BH_PUSH_HI("s67", "CB3")
+        BH_POP_HI("s68", "s44", "s45", "A")
+        BH_POP_HI("s70", "s46", "s47", "B")
         // ---- bucket reference -(node id) - 2: the cell's bodies one by one for the lanes that reached it
         //      (self and exactly coincident bodies contribute nothing: d2 > 0 fails); -1 is dropped
         "Lspecial_%=:\n"
-        "s_cmp_eq_u32 s60, -1\n"
+        "s_cmp_eq_u32 s68, -1\n"
         "s_cbranch_scc1 Lloop_%=\n"
-        "s_sub_i32 s60, -2, s60\n"
-        "s_lshl_b32 s61, s60, 3\n"
-        "s_load_dwordx2 s[58:59], %[aux], s61\n"              // {first sorted body, count}
-        "s_mov_b64 exec, s[56:57]\n"
+        "s_load_dwordx8 s[56:63], %[consts], 0x0\n"              // {aux, sorted positions, sorted masses}: this path only
+        "s_sub_i32 s68, -2, s68\n"
+        "s_lshl_b32 s69, s68, 3\n"
+        "s_mov_b64 exec, s[44:45]\n"
         "s_waitcnt lgkmcnt(0)\n"
-        "s_cmp_lt_i32 s59, 1\n"
+        "s_load_dwordx2 s[48:49], s[56:57], s69\n"              // {first sorted body, count}
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_cmp_lt_i32 s49, 1\n"
         "s_cbranch_scc1 Lloop_%=\n"
-        "s_add_u32 s59, s58, s59\n"
+        "s_add_u32 s49, s48, s49\n"
         "Lbody_%=:\n"
-        "s_lshl_b32 s61, s58, 3\n"
-        "s_load_dwordx2 s[36:37], %[cpos], s61\n"
-        "s_lshl_b32 s61, s58, 2\n"
-        "s_load_dword s44, %[cmass], s61\n"
-        "s_add_u32 s58, s58, 1\n"
+        "s_lshl_b32 s69, s48, 3\n"
+        "s_load_dwordx2 s[50:51], s[58:59], s69\n"
+        "s_lshl_b32 s69, s48, 2\n"
+        "s_load_dword s52, s[60:61], s69\n"
+        "s_add_u32 s48, s48, 1\n"
         "s_waitcnt lgkmcnt(0)\n"
-        "v_pk_add_f32 v[22:23], s[36:37], v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n"
-        "s_cmp_lt_u32 s58, s59\n"                               // loop condition (and the packed result's wait state)
+        "v_pk_add_f32 v[22:23], s[50:51], v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n"
+        "s_cmp_lt_u32 s48, s49\n"                         // loop condition (and the packed result's wait state)
         "v_mul_f32_e32 v24, v23, v23\n"
         "v_fmac_f32_e32 v24, v22, v22\n"
         "v_cmpx_lt_f32_e32 vcc, 0, v24\n"
         "v_rsq_f32_e32 v25, v24\n"
         "s_nop 0\n"                                             // wait state between v_rsq and its use
-        "v_mul_f32_e32 v26, s44, v25\n"
+        "v_mul_f32_e32 v26, s52, v25\n"
         "v_mul_f32_e32 v26, v25, v26\n"
         "v_mul_f32_e32 v24, v25, v26\n"
         "v_fmac_f32_e32 v28, v24, v22\n"
         "v_fmac_f32_e32 v29, v24, v23\n"
-        "s_mov_b64 exec, s[56:57]\n"
+        "s_mov_b64 exec, s[44:45]\n"
         "s_cbranch_scc1 Lbody_%=\n"
         "s_branch Lloop_%=\n"
         "Ldone_%=:\n"
-        "s_mov_b64 exec, s[62:63]\n"
+        "s_mov_b64 exec, -1\n"                                  // (the kernel runs the traversal with all lanes enabled)
         "v_mov_b32_e32 %[ax], v28\n"
         "v_mov_b32_e32 %[ay], v29\n"
-        : [ax] "+v"(ax), [ay] "+v"(ay), [cost] "=&s"(cost)
-        : [quads] "s"(quads), [aux] "s"(aux), [cpos] "s"(cpos), [cmass] "s"(cmass), [root] "s"(root),
-          [every] "s"(everyone), [px] "v"(px), [py] "v"(py), [plim] "s"(pair_limit)
-        : "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
-          "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
-          "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",
-          "s84", "s85", "s86", "s87", "s88", "m0", "vcc", "scc", "memory",
+        : [ax] "+v"(ax), [ay] "+v"(ay), [cost] "=&s"(cost), "+{s68}"(root), "+{s[44:45]}"(everyone)
+        : [quads] "s"(quads), [consts] "s"(consts), [px] "v"(px), [py] "v"(py), [plim] "s"(pair_limit)
+        : "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39",
+          "s40", "s41", "s42", "s43", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+          "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s69", "s70", "s71",
+          "m0", "vcc", "scc", "memory",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35");
     return cost;
 }
@@ -348,6 +349,9 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
     __shared__ float2 f_red[SPLIT > 1 ? SPLIT : 1][SPLIT > 1 ? kWave : 1];
 
     if (a.ctr->overflow) return;
+#ifdef BHGPU_EXPERIMENTS
+    const uint64_t dbg_t0 = a.timeline ? __builtin_amdgcn_s_memrealtime() : 0;     // 100 MHz wall clock
+#endif
     // Workgroup -> group of bodies.  Measured and rejected (kept in -DBHGPU_EXPERIMENTS builds): an
     // XCD-aware placement (workgroups are dealt round-robin over the 8 XCDs, each with its own 4 MiB L2;
     // XCD x takes the x-th CONTIGUOUS eighth of the sorted order) was neutral in round 1 and in round 2
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
             if (t >= 0 && t == a.self_rank) continue;
             int32_t base = (t < 0) ? 0 : (int32_t)(a.forest_base + (int64_t)t * a.let_cap);
             if (ASM) {
-                cost += walk_tree_asm(quads, aux, cpos, cmass, base, everyone, a.pair_limit, p.x, p.y, ax, ay);
+                cost += walk_tree_asm(quads, as_constant(a.bucket_consts), base, everyone, a.pair_limit, p.x, p.y, ax, ay);
                 continue;
             }
             // the C++ statement of walk_tree_asm's loop: same order, same operations
@@ -677,60 +681,82 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
         }
     }
 
+    // Epilogue.  Its arguments are read AGAIN from the kernarg segment through a laundered pointer: the
+    // compiler otherwise loads all ~50 argument dwords up front and keeps the ones used here alive across
+    // the traversal loop, which pushed the kernel to 106 SGPRs = 6 resident waves per SIMD instead of 8
+    // (measured: 6,144 resident waves; the walk is latency-bound, waves are what hides the latency).
+    const WalkFastArgs BH_CONSTANT *ka;
+    {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+        ka = (const WalkFastArgs BH_CONSTANT *)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma clang diagnostic pop
+    }
+    asm volatile("" : "+s"(ka));
+    const WalkFastArgs BH_CONSTANT &e = *ka;
     float2 np = p;
     double2 np64{0.0, 0.0};
-    if (a.part == 1) {
-        if (valid) a.acc_part[s] = float2{ax, ay};              // raw sums; part 2 carries on from here
+    if (e.part == 1) {
+        if (valid) e.acc_part[s] = float2{ax, ay};              // raw sums; part 2 carries on from here
     } else if (valid) {
-        const float gx = a.G * ax, gy = a.G * ay;
-        const uint32_t body = a.perm[s];
-        if (a.acc_out) a.acc_out[body] = float2{gx, gy};
-        if (a.integrate && a.state64) {
+        const float gx = e.G * ax, gy = e.G * ay;
+        const uint32_t body = e.perm[s];
+        if (e.acc_out) e.acc_out[body] = float2{gx, gy};
+        if (e.integrate && e.state64) {
             // mixed precision: the fp32 acceleration advances the fp64 state (updateAccVelPos,
             // project.cu:819-836, in the state's precision)
-            double2 *pos64 = reinterpret_cast<double2 *>(a.pos), *vel64 = reinterpret_cast<double2 *>(a.vel);
+            double2 *pos64 = reinterpret_cast<double2 *>(e.pos), *vel64 = reinterpret_cast<double2 *>(e.vel);
             double2 v = vel64[body];
             const double2 q = pos64[body];
-            v.x = fma((double)gx, (double)a.dt, v.x);
-            v.y = fma((double)gy, (double)a.dt, v.y);
-            np64 = double2{fma(v.x, (double)a.dt, q.x), fma(v.y, (double)a.dt, q.y)};
+            v.x = fma((double)gx, (double)e.dt, v.x);
+            v.y = fma((double)gy, (double)e.dt, v.y);
+            np64 = double2{fma(v.x, (double)e.dt, q.x), fma(v.y, (double)e.dt, q.y)};
             vel64[body] = v;
             pos64[body] = np64;
-        } else if (a.integrate) {
-            float2 v = a.vel[body];
-            v.x = fmaf(gx, a.dt, v.x);
-            v.y = fmaf(gy, a.dt, v.y);
-            np = float2{fmaf(v.x, a.dt, p.x), fmaf(v.y, a.dt, p.y)};
-            if (a.to_sorted) {
-                a.svel[s] = v;
-                a.spos_out[s] = np;
+        } else if (e.integrate) {
+            float2 v = e.vel[body];
+            v.x = fmaf(gx, e.dt, v.x);
+            v.y = fmaf(gy, e.dt, v.y);
+            np = float2{fmaf(v.x, e.dt, p.x), fmaf(v.y, e.dt, p.y)};
+            if (e.to_sorted) {
+                e.svel[s] = v;
+                e.spos_out[s] = np;
             } else {
-                a.vel[body] = v;
-                a.pos[body] = np;
+                e.vel[body] = v;
+                e.pos[body] = np;
             }
         }
     }
     // min/max of the new positions per workgroup: the next step's root box needs no body pass
-    const double bx = a.state64 ? np64.x : (double)np.x, by = a.state64 ? np64.y : (double)np.y;
+    const double bx = e.state64 ? np64.x : (double)np.x, by = e.state64 ? np64.y : (double)np.y;
     if (SPLIT > 1) {
-        if (a.partial && w == 0) {                          // one partial per 64-body group
+        if (e.partial && w == 0) {                          // one partial per 64-body group
             const double xlo = wave_min(valid ? bx : (double)INFINITY), xhi = wave_max(valid ? bx : -(double)INFINITY);
             const double ylo = wave_min(valid ? by : (double)INFINITY), yhi = wave_max(valid ? by : -(double)INFINITY);
             if (lane == 0) {
-                double *o = a.partial + 4 * (size_t)lb;
+                double *o = e.partial + 4 * (size_t)lb;
                 o[0] = xlo; o[1] = xhi; o[2] = ylo; o[3] = yhi;
             }
         }
-    } else if (a.partial) block_bounds_to_partial(valid, bx, by, a.partial + 4 * (size_t)lb);
-    if (a.group_cost && lane == 0 && (SPLIT == 1 || w == 0)) {
-        const int64_t g = (SPLIT > 1 ? a.lo + (int64_t)lb * kWave : a.lo + (int64_t)lb * kBlock + (int64_t)w * kWave) >> 6;
-        if (a.part == 2) a.group_cost[g] += cost;               // the second launch of a split forest walk adds its share
-        else a.group_cost[g] = cost;
+    } else if (e.partial) block_bounds_to_partial(valid, bx, by, e.partial + 4 * (size_t)lb);
+#ifdef BHGPU_EXPERIMENTS
+    if (e.timeline && lane == 0) {                              // per wave: start, end (10 ns ticks), hardware id, cost
+        const int64_t wv = (int64_t)blockIdx.x * (blockDim.x >> 6) + w;
+        e.timeline[4 * wv + 0] = dbg_t0;
+        e.timeline[4 * wv + 1] = __builtin_amdgcn_s_memrealtime();
+        e.timeline[4 * wv + 2] = (uint64_t)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        e.timeline[4 * wv + 3] = cost;
+    }
+#endif
+    if (e.group_cost && lane == 0 && (SPLIT == 1 || w == 0)) {
+        const int64_t g = (SPLIT > 1 ? e.lo + (int64_t)lb * kWave : e.lo + (int64_t)lb * kBlock + (int64_t)w * kWave) >> 6;
+        if (e.part == 2) e.group_cost[g] += cost;               // the second launch of a split forest walk adds its share
+        else e.group_cost[g] = cost;
     }
     if (STATS && lane == 0) {
-        atomicAdd(&a.ctr->visits, n_vis);
-        atomicAdd(&a.ctr->interactions, n_int);
-        atomicAdd(&a.ctr->wave_nodes, n_wave);
+        atomicAdd(&e.ctr->visits, n_vis);
+        atomicAdd(&e.ctr->interactions, n_int);
+        atomicAdd(&e.ctr->wave_nodes, n_wave);
     }
 }
 

@@ -1,0 +1,10 @@
+#!/bin/bash
+# walk_ms of the bench workload under environment switches of the experiments build
+# (python -m gpu_nbody_simulation_amd.build --variant exp -DBHGPU_EXPERIMENTS); usage: scripts/walk_env_ab.sh "VAR=val" ...
+export BHGPU_LIB=$PWD/gpu-nbody-simulation_amd/build/libbhgpu_exp.so
+for setting in "" "$@"; do
+  for rep in 1 2; do
+    env $setting python bench.py --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
+import json,sys; j=json.loads(sys.stdin.read()); print('[$setting]', 'ms/step %.4f walk %.4f build %.4f' % (j['ms_per_step'], j['walk_ms'], j['build_ms']))"
+  done
+done
