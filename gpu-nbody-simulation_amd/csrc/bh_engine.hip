@@ -108,6 +108,9 @@ struct bh_ctx {
     uint32_t *group_cost = nullptr;     // cost of every 64-body group in the last walk (sorted order)
     const void **walk_consts = nullptr; // device block {aux, spos, smass, 0} for the assembly walk's bucket path
     bool group_cost_valid = false;
+    int64_t group_cost_n = 0;           // number of groups group_cost describes
+    bool sort_pack = true;              // BH_SORT_PACK=0: separate key and index arrays in every pass (A/B)
+    bool walk_lpt = true;               // BH_WALK_LPT=0: groups in curve order (A/B)
     unsigned long long *orb_hist = nullptr;
     double *mig_send = nullptr, *mig_recv = nullptr;
 #ifdef BHGPU_EXPERIMENTS
@@ -230,7 +233,16 @@ int enqueue_build_t(bh_ctx *c)
 
     if (n > 0) {
         // 2. keys by fp64 bisection, 3. stable radix sort
-        if (c->hilbert)
+        // keys of <= 40 bits for <= 2^24 bodies carry the body index in the key word through the sort
+        const bool pack = c->hilbert && Dm >= 1 && 2 * Dm <= kPackShift && n <= ((int64_t)1 << (64 - kPackShift)) && c->sort_wave_rank
+#ifdef BHGPU_EXPERIMENTS
+                          && !c->sort_onesweep
+#endif
+                          && c->sort_pack;
+        if (pack)
+            hipLaunchKernelGGL((keys_kernel<Real2, true, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
+                               c->box, c->keys[0], c->vals[0], n, Dm);
+        else if (c->hilbert)
             hipLaunchKernelGGL((keys_kernel<Real2, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
                                c->box, c->keys[0], c->vals[0], n, Dm);
         else
@@ -265,9 +277,16 @@ int enqueue_build_t(bh_ctx *c)
                 hipLaunchKernelGGL((radix_hist<SI, SB>), dim3(nbl), dim3(kBlock), 0, st, c->keys[cur], c->radix_counts, n,
                                    shift, (int)nbl);
                 hipLaunchKernelGGL(radix_rowscan, dim3(SR), dim3(kBlock), 0, st, c->radix_counts, c->bsum_sort, (int)nbl);
-                hipLaunchKernelGGL((radix_scatter_w<SI, SB>), dim3(nbl), dim3(kBlock), 0, st, c->keys[cur], c->vals[cur],
-                                   c->keys[cur ^ 1], c->vals[cur ^ 1], c->radix_counts, c->bsum_sort, n, shift,
-                                   (int)nbl);
+                if (pack && p + 1 < passes)
+                    hipLaunchKernelGGL((radix_scatter_w<SI, SB, 1>), dim3(nbl), dim3(kBlock), 0, st, c->keys[cur], c->vals[cur],
+                                       c->keys[cur ^ 1], c->vals[cur ^ 1], c->radix_counts, c->bsum_sort, n, shift, (int)nbl);
+                else if (pack)
+                    hipLaunchKernelGGL((radix_scatter_w<SI, SB, 2>), dim3(nbl), dim3(kBlock), 0, st, c->keys[cur], c->vals[cur],
+                                       c->keys[cur ^ 1], c->vals[cur ^ 1], c->radix_counts, c->bsum_sort, n, shift, (int)nbl);
+                else
+                    hipLaunchKernelGGL((radix_scatter_w<SI, SB>), dim3(nbl), dim3(kBlock), 0, st, c->keys[cur], c->vals[cur],
+                                       c->keys[cur ^ 1], c->vals[cur ^ 1], c->radix_counts, c->bsum_sort, n, shift,
+                                       (int)nbl);
                 cur ^= 1;
             }
         }
@@ -518,6 +537,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
 #endif
     if (const char *e = std::getenv("BH_WALK_SPLIT")) c->walk_split = std::atoi(e);
     if (const char *e = std::getenv("BH_WALK_ASM")) c->walk_asm = std::atoi(e) != 0;
+    if (const char *e = std::getenv("BH_SORT_PACK")) c->sort_pack = std::atoi(e) != 0;
     if (const char *e = std::getenv("BH_BUILD_ITEMS")) c->build_items = std::atoi(e);
     if (const char *e = std::getenv("BH_REORDER_EVERY")) c->reorder_every = std::max(0, std::atoi(e));
     c->hilbert = !c->exact;

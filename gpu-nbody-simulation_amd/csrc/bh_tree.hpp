@@ -130,7 +130,8 @@ __host__ __device__ __forceinline__ int hilbert_next(int state, int c) { return 
 // change.  64 consecutive bodies then form a more compact patch, and a wavefront touches ~7 %
 // fewer distinct nodes (measured with the oracle: U64 13.99 -> 13.08 Plummer, 10.79 -> 9.97
 // uniform).  Exact mode keeps child-index order (the reference's depth-cap fold follows it).
-template <typename Real2, bool HILBERT>
+// PACK: the body index is written into bits 40..63 of the key word instead of the index array (bh_sort.hpp)
+template <typename Real2, bool HILBERT, bool PACK = false>
 __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ pos,
                                                        const double *__restrict__ box,
                                                        uint64_t *__restrict__ keys,
@@ -171,8 +172,12 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
             descend(c, mx, my, x0, x1, y0, y1);
         }
     }
-    keys[i] = k;
-    idx[i] = (uint32_t)i;
+    if (PACK) {
+        keys[i] = k | ((uint64_t)i << kPackShift);
+    } else {
+        keys[i] = k;
+        idx[i] = (uint32_t)i;
+    }
 }
 
 // ---- after the sort: cell counts per sorted body (+ fp32: sorted copies and prefix-sum terms) ----

@@ -45,23 +45,29 @@ def test_struct_layouts_match_the_header(tmp_path):
     prog = tmp_path / "layout.c"
     fields_cfg = [f[0] for f in _lib.bh_config._fields_]
     fields_st = [f[0] for f in _lib.bh_stats_t._fields_]
+    fields_oc = [f[0] for f in _lib.bh_orb_cuts._fields_]
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){",
-             'printf("%zu %zu %zu\\n", sizeof(bh_config), sizeof(bh_tree_node), sizeof(bh_stats_t));']
+             'printf("%zu %zu %zu %zu\\n", sizeof(bh_config), sizeof(bh_tree_node), sizeof(bh_stats_t), sizeof(bh_orb_cuts));']
     for f in fields_cfg:
         lines.append(f'printf("%zu\\n", offsetof(bh_config, {f}));')
     for f in fields_st:
         lines.append(f'printf("%zu\\n", offsetof(bh_stats_t, {f}));')
+    for f in fields_oc:
+        lines.append(f'printf("%zu\\n", offsetof(bh_orb_cuts, {f}));')
     lines.append("return 0;}")
     prog.write_text("\n".join(lines))
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c11", "-o", str(exe), str(prog)])
     out = subprocess.check_output([str(exe)]).decode().split()
-    sizes, offs = list(map(int, out[:3])), list(map(int, out[3:]))
-    assert sizes == [C.sizeof(_lib.bh_config), C.sizeof(_lib.bh_tree_node), C.sizeof(_lib.bh_stats_t)]
+    sizes, offs = list(map(int, out[:4])), list(map(int, out[4:]))
+    assert sizes == [C.sizeof(_lib.bh_config), C.sizeof(_lib.bh_tree_node), C.sizeof(_lib.bh_stats_t),
+                     C.sizeof(_lib.bh_orb_cuts)]
     assert sizes[1] == 96                                     # the reference's 12-double Quadrant
     want = [getattr(_lib.bh_config, f).offset for f in fields_cfg] + \
-           [getattr(_lib.bh_stats_t, f).offset for f in fields_st]
+           [getattr(_lib.bh_stats_t, f).offset for f in fields_st] + \
+           [getattr(_lib.bh_orb_cuts, f).offset for f in fields_oc]
     assert offs == want
+    assert _lib.ORB_BINS == 4096 and _lib.ORB_MAX_CUTS == 63   # BH_ORB_BINS / BH_ORB_MAX_CUTS
 
 
 def test_header_is_plain_c():

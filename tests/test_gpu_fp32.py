@@ -114,6 +114,31 @@ def test_asm_walk_equals_the_portable_walk(kind, n, md, compat):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("kind,n,md", [("plummer", 200000, 21), ("clumped", 30000, 8), ("uniform", 513, 3)])
+def test_packed_sort_equals_the_two_array_sort(monkeypatch, kind, n, md):
+    """Keys of <= 40 bits carry the body index in the key word through the radix passes (one 8-byte array per
+    pass instead of key + index arrays; BH_SORT_PACK=0 restores the two arrays).  Same stable order, so the
+    tree, the forces and a moving trajectory are BITWISE the same -- equal keys (bodies sharing a depth-cap
+    cell: the clumped case) keep their body order either way."""
+    if kind == "clumped":
+        rng = np.random.default_rng(5)
+        p = f32(np.concatenate([rng.normal(0, 1e-3, (n // 2, 2)), rng.uniform(-1, 1, (n - n // 2, 2))]))
+        m, v = f32(rng.uniform(0.1, 0.5, n)), f32(rng.normal(0, 1e-4, (n, 2)))
+    else:
+        m, p, v = IC.make(kind, n, 3, quasi_static=True, drift_cells=1.0)
+    res = []
+    for packv in ("1", "0"):
+        monkeypatch.setenv("BH_SORT_PACK", packv)
+        with engine(n, max_depth=md, reference_compat=False) as e:
+            e.upload(p, v, m)
+            e.build_tree()
+            nodes, depth = e.export_tree()
+            e.step(20)                                             # crosses a re-ordering of the state (every 16th build)
+            res.append((nodes, depth) + e.download())
+    for x, y in zip(res[0], res[1]):
+        assert np.array_equal(x, y)
+
+
 def test_multistep_trajectory_encounter_free_case(gold):
     """20 steps vs the REFERENCE's own trajectory (golden; encounter-free by construction, see
     scripts/make_golden.py): positions <= 1e-6 x box width; the velocity CHANGE (what the forces did)
