@@ -33,6 +33,14 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 NODE_BYTES = 20         # fp32 node: one quarter of the 80-byte sibling-quad record (bh_nodes.hpp QuadF)
+# Issue-rate roofline of the walk.  Cycles of one SIMD per wave-instruction, measured
+# with 8 waves per SIMD by scripts/calib/issue_calib.hip (profiles/r02_final/issue_calib.txt): plain fp32
+# VALU 2.2; VALU with an SGPR operand, v_pk_*_f32, v_cmp/v_cmpx, v_writelane, v_readfirstlane 4.1-4.3;
+# v_rsq_f32 8.3.  Per evaluated child the loop issues v_pk_add(s) + v_mul + v_fmac + v_cmpx + v_rsq +
+# v_mul(s) + 2 v_mul + 2 v_fmac; per quad 3 v_readfirstlane (pop) and ~1 push of 3 v_writelane.
+VALU_CYCLES_PER_CHILD = 4.2 + 2.2 + 2.2 + 4.3 + 8.3 + 4.2 + 2.2 + 2.2 + 2.2 + 2.2
+VALU_CYCLES_PER_QUAD = 3 * 4.1 + 3 * 4.2
+N_SIMDS, SHADER_CLOCK_HZ = 1024, 2.4e9
 
 
 def parse():
@@ -323,6 +331,15 @@ def main():
                     "traffic_source_digest": tdig, "source_digest": digest,
                     "kernel": "walk_fast_kernel", "kernel_ms": walk_ms,
                     "algorithmic_bytes_per_launch": walk_bytes, "u64_nodes_per_body": u64}
+            # the fraction of the SIMDs' vector-issue cycles the kernel's instruction mix needs (the walk is
+            # an irregular gather: it is bounded by memory LATENCY and vector issue, not by bytes)
+            wq = getattr(ss, "wave_quads", 0)
+            if wq:
+                valu = ss.wave_nodes * VALU_CYCLES_PER_CHILD + wq * VALU_CYCLES_PER_QUAD
+                roof["issue_frac"] = valu / (N_SIMDS * walk_ms * 1e-3 * SHADER_CLOCK_HZ)
+                roof["issue"] = {"valu_cycles_per_launch": valu, "simd_cycles_per_launch": N_SIMDS * walk_ms * 1e-3 * SHADER_CLOCK_HZ,
+                                 "quads_per_launch": wq, "children_per_launch": ss.wave_nodes,
+                                 "cycles_per_child": VALU_CYCLES_PER_CHILD, "cycles_per_quad": VALU_CYCLES_PER_QUAD}
         out = {
             "metric": "body-steps/sec", "value": value, "unit": "body-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -451,12 +451,13 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         a.pair_limit = std::max(0, 120 - 3 * c->Dm);
         const int mode = c->let_mode ? 0 : c->walk_mode;
         // few bodies: several waves per 64-body group (bh_walk_fast.hip).  Measured best factor
-        // (scripts/split_sweep.py): 8 up to 32k bodies per launch, 4 up to 192k,
-        // one wave per group beyond.  BH_WALK_SPLIT overrides (1 = off).
+        // (scripts/split_ab.sh): 8 up to 32k bodies per launch, 4 up to ~100k, one wave
+        // per group -- the hand-scheduled loop with two quads in flight -- beyond (round 1's compiled loop
+        // lost to the split walk up to 192k; at 131k: 0.097 against 0.102 ms).  BH_WALK_SPLIT overrides (1 = off).
         int split = (c->cfg.flags & BH_FLAG_WALK_NO_SPLIT) ? 1 : c->walk_split;
         if (split <= 0) {
             const int64_t groups = (hi - lo + kWave - 1) / kWave;
-            split = groups <= 512 ? 8 : groups <= 3072 ? 4 : 1;
+            split = groups <= 512 ? 8 : groups <= 1600 ? 4 : 1;
         }
         if (3 * c->Dm + 2 > kWave) split = 1;        // the level-synchronous walk's depth-first fallback has 64 entries
         // hand-scheduled loop: byte offsets into the quad array and the sorted bodies are 32-bit there
@@ -1022,6 +1023,7 @@ int bh_stats(bh_ctx *c, bh_stats_t *out)
         out->visits = h.visits;
         out->interactions = h.interactions;
         out->wave_nodes = h.wave_nodes;
+        out->wave_quads = h.wave_quads;
     }
     if (c->step_timed) {
         float ms = 0.f;

@@ -41,6 +41,7 @@ struct TreeCounters {
     uint32_t pad[2];
     unsigned long long visits, interactions;
     unsigned long long wave_nodes;   // nodes evaluated by wavefronts (one count per wave per node)
+    unsigned long long wave_quads;   // sibling quads loaded by wavefronts (one count per wave per quad)
 };
 
 }  // namespace bh

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void bounds_final(const double *__restrict_
         if (span == 0.0) pad = 1e-6;
         box[0] = xlo - pad; box[1] = xhi + pad; box[2] = ylo - pad; box[3] = yhi + pad;
         ctr->n_internal = 0; ctr->overflow = 0;
-        ctr->visits = 0; ctr->interactions = 0; ctr->wave_nodes = 0;
+        ctr->visits = 0; ctr->interactions = 0; ctr->wave_nodes = 0; ctr->wave_quads = 0;
     }
 }
 

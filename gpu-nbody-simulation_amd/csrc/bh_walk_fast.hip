@@ -374,7 +374,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
     float ax = 0.f, ay = 0.f;
     if (a.part == 2 && valid && (SPLIT == 1 || w == 0)) { const float2 t = a.acc_part[s]; ax = t.x; ay = t.y; }
     asm volatile("" : "+v"(ax), "+v"(ay));                // (same for this load: no s_waitcnt vmcnt in the loop)
-    unsigned long long n_vis = 0, n_int = 0, n_wave = 0;
+    unsigned long long n_vis = 0, n_int = 0, n_wave = 0, n_quad = 0;
     uint32_t cost = 0;                                       // loop iterations of this group's walk (re-balancing weight)
 
     const QuadF BH_CONSTANT *quads = as_constant(a.quads);
@@ -430,6 +430,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
     };
 
     auto eval_quad = [&](const QuadRegs &q, const uint64_t mask) {
+        if (STATS) ++n_quad;
         eval(__int_as_float(q.g[0]), __int_as_float(q.g[1]), q.g[8], __int_as_float(q.g[12]), q.c[0], mask);
         eval(__int_as_float(q.g[2]), __int_as_float(q.g[3]), q.g[9], __int_as_float(q.g[13]), q.c[1], mask);
         eval(__int_as_float(q.g[4]), __int_as_float(q.g[5]), q.g[10], __int_as_float(q.g[14]), q.c[2], mask);
@@ -757,6 +758,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
         atomicAdd(&e.ctr->visits, n_vis);
         atomicAdd(&e.ctr->interactions, n_int);
         atomicAdd(&e.ctr->wave_nodes, n_wave);
+        atomicAdd(&e.ctr->wave_quads, n_quad);
     }
 }
 

@@ -70,6 +70,7 @@ class BhStats:
     nodes_ms: float = 0.0
     build_bytes: int = 0        # algorithmic bytes of that step
     walk_bytes: int = 0
+    wave_quads: int = 0         # FLAG_WALK_STATS: quads loaded, once per wavefront
 
 
 def _dptr(a: np.ndarray):
@@ -190,7 +191,7 @@ class BarnesHutEngine:
         self._check(self._lib.bh_stats(self._h, C.byref(s)))
         return BhStats(s.n_bodies, s.n_nodes, s.n_internal, s.steps_done, s.visits, s.interactions,
                        s.wave_nodes, s.last_step_ms, s.build_ms, s.walk_ms, s.device_bytes, s.keys_ms, s.sort_ms,
-                       s.scan_ms, s.nodes_ms, s.build_bytes, s.walk_bytes)
+                       s.scan_ms, s.nodes_ms, s.build_bytes, s.walk_bytes, s.wave_quads)
 
     # -- multi-GPU plumbing -----------------------------------------------------------------
     def set_owned_fraction(self, rank: int, world: int) -> None:

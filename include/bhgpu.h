@@ -58,7 +58,7 @@ typedef enum bh_precision {
 #define BH_FLAG_LDS_STACK    (1u << 1)  /* fp32 walk: LDS traversal stack instead of the
                                            register-lane stack (A/B switch)  */
 #define BH_FLAG_WALK_NO_SPLIT (1u << 2) /* fp32 walk: always one wavefront per 64 bodies.  By
-                                           default a launch of few bodies (<= 192k: small N, or
+                                           default a launch of few bodies (<= ~100k: small N, or
                                            one rank's share) lets 4 or 8 wavefronts share each
                                            64-body group, level by level; same nodes, same
                                            per-body criterion, but another order of the fp32
@@ -128,6 +128,8 @@ typedef struct bh_stats_t {
     uint64_t build_bytes;        /* keys + sort passes + scan + nodes                        */
     uint64_t walk_bytes;         /* walk + integrate: 44 B per body + 20 B per node a
                                     wavefront evaluates (needs BH_FLAG_WALK_STATS, else 0)    */
+    uint64_t wave_quads;         /* BH_FLAG_WALK_STATS: sibling quads loaded, counted once per
+                                    wavefront (the walk's memory round trips)                 */
 } bh_stats_t;
 
 typedef struct bh_ctx bh_ctx;
