@@ -235,10 +235,22 @@ def main():
         stepper = ShardedStepper(eng, rank, world, n, dev, force_exchange=a.force_sharded)
 
     def sync_all():
-        eng.sync()
+        """Wait for this rank's stream, then for everybody -- and FAIL TOGETHER: a rank whose tree or LET
+        outgrew its capacity raises from eng.sync(); were it to leave alone, the others would wait in the
+        next collective for ever.  The all_reduce of the failure flag is the barrier."""
+        err = None
+        try:
+            eng.sync()
+        except Exception as ex:                       # noqa: BLE001 -- re-raised below, on every rank
+            err = ex
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev if a.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()) and err is None:
+                err = RuntimeError("another rank failed (its message is on its own stderr)")
+        if err is not None:
+            raise err
 
     for _ in range(a.warmup):
         stepper.step()

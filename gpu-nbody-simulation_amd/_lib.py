@@ -89,7 +89,7 @@ SIGNATURES = {
                                   C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "bh_owned_range": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "bh_step_local": (C.c_int, [_ctx]),
-    "bh_device_sorted": (C.c_int, [_ctx, C.POINTER(_vp), C.POINTER(_vp)]),
+    "bh_device_sorted": (C.c_int, [_ctx, C.POINTER(_vp)]),
     "bh_scatter_sorted": (C.c_int, [_ctx]),
     "bh_set_stream": (C.c_int, [_ctx, _vp]),
     "bh_let_local_quads": (C.c_int, [_ctx, C.POINTER(C.c_int64)]),

@@ -65,7 +65,8 @@ struct bh_ctx {
     int reorder_every = 16;        // BH_REORDER_EVERY; 0 = never
     int64_t builds = 0;            // builds since the last upload
     // sorted-order copies (fp32 mode)
-    float2 *spos = nullptr, *spos_out = nullptr, *svel = nullptr;
+    float2 *spos = nullptr;
+    float4 *sstate = nullptr;      // sorted-order {x, y, vx, vy}: the replicated scheme's one exchange buffer
     float *smass = nullptr;
     // sort
     uint64_t *keys[2] = {nullptr, nullptr};
@@ -432,7 +433,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         a.quads = c->qf; a.aux = c->aux; a.partial = partial; a.spos = c->spos; a.smass = c->smass; a.perm = c->perm;
         a.pos = (float2 *)c->pos; a.vel = (float2 *)c->vel;
         a.state64 = c->state64 ? 1 : 0;               // mixed precision: pos/vel point at double2 arrays
-        a.spos_out = c->spos_out; a.svel = c->svel;
+        a.sstate = c->sstate;
         a.acc_out = (float2 *)c->force; a.ctr = c->ctr;
         a.lo = lo; a.hi = hi; a.G = (float)c->cfg.G; a.dt = (float)c->cfg.dt;
         a.integrate = integrate ? 1 : 0; a.to_sorted = to_sorted ? 1 : 0;
@@ -597,7 +598,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
         A(&c->cell_first, c->internal_cap + 1);
         A(&c->gid, cap); A(&c->group_cost, cap / kWave + 2); A(&c->walk_consts, 4);
         A(&c->coarse, cap / 256 + 2);
-        A(&c->spos, cap); A(&c->spos_out, cap + 64 * kBlock + 1024); A(&c->svel, cap + 64 * kBlock + 1024); A(&c->smass, cap);
+        A(&c->spos, cap); A(&c->sstate, cap + 64 * kBlock + 1024); A(&c->smass, cap);
         A(&c->terms, cap + 1); A(&c->bsum_d3, std::max<size_t>(blocks_for(cap + 1, kTile), blocks_for(std::min<int64_t>(cap, 1 << 22) + 1, kBlock * kSmallItems)) + 8);
     }
     if (rc) return bail(rc);
@@ -1078,12 +1079,11 @@ int bh_device_state(bh_ctx *c, void **pos, void **vel, void **mass, int64_t *n, 
     return BH_OK;
 }
 
-int bh_device_sorted(bh_ctx *c, void **sorted_pos, void **sorted_vel)
+int bh_device_sorted(bh_ctx *c, void **sorted_state)
 {
     if (!c) return BH_ERR_ARG;
-    if (c->state64) return fail(c, BH_ERR_STATE, "sorted exchange buffers exist in fp32 mode only");
-    if (sorted_pos) *sorted_pos = c->spos_out;
-    if (sorted_vel) *sorted_vel = c->svel;
+    if (c->state64) return fail(c, BH_ERR_STATE, "the sorted exchange buffer exists in fp32 mode only");
+    if (sorted_state) *sorted_state = c->sstate;
     return BH_OK;
 }
 
@@ -1091,16 +1091,16 @@ int bh_device_sorted(bh_ctx *c, void **sorted_pos, void **sorted_vel)
 
 namespace bh {
 __global__ __launch_bounds__(kBlock) void scatter_sorted_kernel(const uint32_t *__restrict__ perm,
-                                                                 const float2 *__restrict__ spos,
-                                                                 const float2 *__restrict__ svel,
+                                                                 const float4 *__restrict__ sstate,
                                                                  float2 *__restrict__ pos,
                                                                  float2 *__restrict__ vel, int64_t n)
 {
     const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (s >= n) return;
     const uint32_t b = perm[s];
-    pos[b] = spos[s];
-    vel[b] = svel[s];
+    const float4 t = sstate[s];
+    pos[b] = float2{t.x, t.y};
+    vel[b] = float2{t.z, t.w};
 }
 }  // namespace bh
 
@@ -1124,7 +1124,7 @@ int bh_scatter_sorted(bh_ctx *c)
     BH_HIP(c, hipSetDevice(c->device));
     if (c->n > 0) {
         hipLaunchKernelGGL(scatter_sorted_kernel, dim3(blocks_for(c->n, kBlock)), dim3(kBlock), 0, c->stream,
-                           c->perm, c->spos_out, c->svel, (float2 *)c->pos, (float2 *)c->vel, c->n);
+                           c->perm, c->sstate, (float2 *)c->pos, (float2 *)c->vel, c->n);
         BH_HIP(c, hipGetLastError());
     }
     c->partial_count = 0;

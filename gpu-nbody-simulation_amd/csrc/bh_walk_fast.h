@@ -21,7 +21,7 @@ struct WalkFastArgs {
     float2 *pos, *vel;         // caller-order state (updated when integrate && !to_sorted);
                                // double2 arrays when state64 (mixed precision)
     int32_t state64;
-    float2 *spos_out, *svel;   // sorted-order outputs (integrate && to_sorted)
+    float4 *sstate;            // sorted-order output {x, y, vx, vy} per body (integrate && to_sorted): ONE exchange buffer
     float2 *acc_out;           // caller-order accelerations, may be null
     TreeCounters *ctr;
     double *partial;           // per-workgroup min/max of the new positions, may be null

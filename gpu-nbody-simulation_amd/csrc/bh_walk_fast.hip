@@ -720,8 +720,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
             v.y = fmaf(gy, e.dt, v.y);
             np = float2{fmaf(v.x, e.dt, p.x), fmaf(v.y, e.dt, p.y)};
             if (e.to_sorted) {
-                e.svel[s] = v;
-                e.spos_out[s] = np;
+                e.sstate[s] = float4{np.x, np.y, v.x, v.y};
             } else {
                 e.vel[body] = v;
                 e.pos[body] = np;

@@ -297,7 +297,8 @@ def _bind_engine_stream(engine, device) -> None:
 
 
 class ShardedStepper:
-    """step() = local build + walk of the owned sorted range, all_gather, scatter to caller order."""
+    """step() = local build + walk of the owned sorted range, ONE in-place all_gather of {x, y, vx, vy},
+    scatter to caller order."""
 
     def __init__(self, engine, rank: int, world: int, n: int, device: torch.device | None = None,
                  force_exchange: bool = False):
@@ -314,34 +315,33 @@ class ShardedStepper:
         assert (lo, hi) == (min(n, self.chunk * rank), min(n, self.chunk * (rank + 1)))
         self.lo, self.hi = lo, hi
         if self.exchange:
-            sp, sv = engine.device_sorted()
-            nel = 2 * self.chunk * world        # float2 per body; buffers hold chunk*world slots
-            if isinstance(sp, torch.Tensor):    # stand-in engines hand tensors over directly
-                self.spos, self.svel = sp, sv
-            else:
-                self.spos = wrap_device_f32(sp, nel, device)
-                self.svel = wrap_device_f32(sv, nel, device)
+            st = engine.device_sorted()
+            nel = 4 * self.chunk * world        # {x, y, vx, vy} per body; the buffer holds chunk*world slots
+            # stand-in engines hand a tensor over directly
+            self.sstate = st if isinstance(st, torch.Tensor) else wrap_device_f32(st, nel, device)
 
     def step(self) -> None:
         if not self.exchange:
             self.eng.step(1)
             return
         self.eng.step_local()
-        c2 = 2 * self.chunk
-        for buf in (self.spos, self.svel):
-            # fixed-size block per rank; the send block is a copy so the collective never aliases
-            # its own output (2 MB per rank at N = 1M on 8 ranks)
-            mine = buf[self.rank * c2:(self.rank + 1) * c2].clone()
-            if dist.is_initialized() and buf.is_cuda and dist.get_backend() == "gloo":
-                # rehearsal only (several ranks sharing one GPU, where RCCL cannot run): through the host
-                self.eng.sync()
-                out = torch.empty(self.world * c2, dtype=buf.dtype)
-                dist.all_gather_into_tensor(out, mine.cpu())
-                buf[: self.world * c2].copy_(out)
-            elif dist.is_initialized():
-                dist.all_gather_into_tensor(buf[: self.world * c2], mine)
-            else:
-                assert self.world == 1
+        c4 = 4 * self.chunk
+        buf = self.sstate
+        mine = buf[self.rank * c4:(self.rank + 1) * c4]
+        if dist.is_initialized() and buf.is_cuda and dist.get_backend() == "gloo":
+            # rehearsal only (several ranks sharing one GPU, where RCCL cannot run): through the host
+            self.eng.sync()
+            out = torch.empty(self.world * c4, dtype=buf.dtype)
+            dist.all_gather_into_tensor(out, mine.cpu())
+            buf[: self.world * c4].copy_(out)
+        elif dist.is_initialized() and not buf.is_cuda:
+            dist.all_gather_into_tensor(buf[: self.world * c4], mine.clone())      # gloo: no in-place form
+        elif dist.is_initialized():
+            # ONE collective per step, in place: rank r's block already sits at block r of the buffer
+            # (the in-place form of ncclAllGather: sendbuff == recvbuff + rank * count), 16 B per body
+            dist.all_gather_into_tensor(buf[: self.world * c4], mine)
+        else:
+            assert self.world == 1
         self.eng.scatter_sorted()
 
 

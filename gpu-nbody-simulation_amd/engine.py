@@ -209,9 +209,10 @@ class BarnesHutEngine:
         self._check(self._lib.bh_scatter_sorted(self._h))
 
     def device_sorted(self):
-        p, v = C.c_void_p(), C.c_void_p()
-        self._check(self._lib.bh_device_sorted(self._h, C.byref(p), C.byref(v)))
-        return p.value, v.value
+        """Device pointer of the sorted-order exchange buffer: {x, y, vx, vy} float32 per sorted body."""
+        p = C.c_void_p()
+        self._check(self._lib.bh_device_sorted(self._h, C.byref(p)))
+        return p.value
 
     def device_state(self):
         p, v, m = C.c_void_p(), C.c_void_p(), C.c_void_p()

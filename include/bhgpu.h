@@ -210,11 +210,11 @@ int bh_set_owned_fraction(bh_ctx *ctx, int32_t rank, int32_t world);
 int bh_device_state(bh_ctx *ctx, void **pos, void **vel, void **mass, int64_t *n,
                     int32_t *elem_bytes);
 int bh_owned_range(bh_ctx *ctx, int64_t *lo, int64_t *hi);
-/* Sorted-order views used by the exchange: after bh_step_local the owned slice of
- * sorted_pos/sorted_vel holds the new state; bh_scatter_sorted writes the full sorted
- * arrays (after the all_gather) back to caller order. */
+/* Sorted-order view used by the exchange: ONE buffer of {x, y, vx, vy} (4 floats) per sorted body.
+ * After bh_step_local the owned slice holds the new state; after ONE all_gather of the slices
+ * bh_scatter_sorted writes the whole buffer back to caller order. */
 int bh_step_local(bh_ctx *ctx);
-int bh_device_sorted(bh_ctx *ctx, void **sorted_pos, void **sorted_vel);
+int bh_device_sorted(bh_ctx *ctx, void **sorted_state);
 int bh_scatter_sorted(bh_ctx *ctx);
 /* Distributed step with locally-essential trees (LET).  Unlike the replicated scheme above, a
  * context in LET mode holds ONLY ITS OWN bodies (bh_upload its subset; a contiguous range of a

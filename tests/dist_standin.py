@@ -32,15 +32,14 @@ class OracleStandInEngine:
     def set_owned_fraction(self, rank, world):
         self.rank, self.world = rank, world
         chunk = ((self.n + world - 1) // world + 255) // 256 * 256
-        self.spos = torch.zeros(2 * chunk * world, dtype=torch.float32)
-        self.svel = torch.zeros(2 * chunk * world, dtype=torch.float32)
+        self.sstate = torch.zeros(4 * chunk * world, dtype=torch.float32)
 
     def owned_range(self):
         chunk = ((self.n + self.world - 1) // self.world + 255) // 256 * 256
         return min(self.n, chunk * self.rank), min(self.n, chunk * (self.rank + 1))
 
     def device_sorted(self):
-        return self.spos, self.svel
+        return self.sstate
 
     def _accel(self, lo, hi):
         p64, m64 = self.pos.astype(np.float64), self.mass.astype(np.float64)
@@ -59,22 +58,21 @@ class OracleStandInEngine:
         acc, idx = self._accel(lo, hi)
         v = self.vel[idx] + (acc[idx] * self.dt).astype(np.float32)
         p = self.pos[idx] + v * np.float32(self.dt)
-        self.spos[2 * lo:2 * hi] = torch.from_numpy(p.reshape(-1))
-        self.svel[2 * lo:2 * hi] = torch.from_numpy(v.reshape(-1))
+        self.sstate[4 * lo:4 * hi] = torch.from_numpy(np.concatenate([p, v], axis=1).astype(np.float32).reshape(-1))
 
     def scatter_sorted(self):
         n = self.n
-        self.pos[self.perm] = self.spos[:2 * n].numpy().reshape(n, 2)
-        self.vel[self.perm] = self.svel[:2 * n].numpy().reshape(n, 2)
+        st = self.sstate[:4 * n].numpy().reshape(n, 4)
+        self.pos[self.perm] = st[:, 0:2]
+        self.vel[self.perm] = st[:, 2:4]
 
     def step(self, k=1):
         for _ in range(k):
             saved = (self.rank, self.world)
             self.rank, self.world = 0, 1
             chunk = self.n
-            if self.spos.numel() < 2 * chunk:
-                self.spos = torch.zeros(2 * chunk)
-                self.svel = torch.zeros(2 * chunk)
+            if self.sstate.numel() < 4 * chunk:
+                self.sstate = torch.zeros(4 * chunk)
             self.step_local()
             self.scatter_sorted()
             self.rank, self.world = saved

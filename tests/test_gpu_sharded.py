@@ -41,19 +41,17 @@ def test_emulated_ranks_equal_single_context(n, world, no_split):
         e.upload(p, v, m)
         e.set_owned_fraction(r, world)
         assert e.owned_range() == (min(n, r * chunk), min(n, (r + 1) * chunk))
-        sp, sv = e.device_sorted()
-        bufs.append((wrap_device_f32(sp, 2 * chunk * world, dev), wrap_device_f32(sv, 2 * chunk * world, dev)))
+        bufs.append(wrap_device_f32(e.device_sorted(), 4 * chunk * world, dev))
     for step in range(3):
         ref.step(1)
         for e in engs:
             e.step_local()
             e.sync()
         for r in range(world):                       # "all_gather": every rank receives every slice
-            lo, hi = 2 * r * chunk, 2 * (r + 1) * chunk
+            lo, hi = 4 * r * chunk, 4 * (r + 1) * chunk
             for q in range(world):
                 if q != r:
-                    bufs[q][0][lo:hi].copy_(bufs[r][0][lo:hi])
-                    bufs[q][1][lo:hi].copy_(bufs[r][1][lo:hi])
+                    bufs[q][lo:hi].copy_(bufs[r][lo:hi])
         torch.cuda.synchronize()
         for e in engs:
             e.scatter_sorted()
