@@ -88,7 +88,7 @@ struct bh_ctx {
     LinkD *ld = nullptr;
     QuadF *qf = nullptr;
     NodeAux *aux = nullptr;
-    int32_t *self_node = nullptr;
+    int32_t *self_node = nullptr, *cell_depth = nullptr;
     uint32_t *com_pending = nullptr;   // exact mode: subdivided children per cell still to be summed
     TreeCounters *ctr = nullptr;
 
@@ -185,6 +185,7 @@ void owned_range(const bh_ctx *c, int64_t *lo, int64_t *hi)
     *hi = std::min<int64_t>(c->n, chunk * (c->rank + 1));
 }
 
+constexpr int64_t kComClimbMaxBodies = 32768;     // exact mode: single-launch bottom-up mass pass up to here
 constexpr int64_t kSmallBuildBodies = 327680;    // up to here: tiles of 512 instead of 2,048 (measured)
 constexpr int64_t kMediumBuildBodies = 786432;   // up to here: tiles of 1,024
 constexpr int kSmallItems = 2;
@@ -358,10 +359,12 @@ int enqueue_build_t(bh_ctx *c)
     }
 
     // 6. nodes (thread 0 writes the root when nothing is subdivided)
-    const unsigned nbn = blocks_for(std::max<int64_t>(n, 1), kBlock);
     if constexpr (EXACT) {
-        hipLaunchKernelGGL(nodes_exact_kernel, dim3(nbn), dim3(kBlock), 0, st, c->keys_sorted, c->perm, c->cnt, pos,
-                           mass, c->box, n, Dm, c->internal_cap, c->gd, c->ld, c->self_node, c->com_pending, c->ctr);
+        // one thread per subdivided cell; I <= (n-1)*Dm and <= internal_cap (at least one thread: the root-only case)
+        const int64_t span = std::max<int64_t>(1, std::min<int64_t>(c->internal_cap, std::max<int64_t>(n - 1, 0) * (int64_t)std::max(1, Dm)));
+        hipLaunchKernelGGL(nodes_exact_kernel, dim3(blocks_for(span, kBlock)), dim3(kBlock), 0, st, c->keys_sorted, c->perm,
+                           c->cnt, c->cell_first, pos, mass, c->box, n, Dm, c->internal_cap, c->gd, c->ld, c->self_node,
+                           c->cell_depth, c->com_pending, c->ctr);
     } else {
         // one thread per subdivided cell; I <= (n-1)*Dm and <= internal_cap
         const int64_t span = std::max<int64_t>(1, std::min<int64_t>(c->internal_cap, std::max<int64_t>(n - 1, 0) * (int64_t)std::max(1, Dm)));
@@ -375,11 +378,19 @@ int enqueue_build_t(bh_ctx *c)
                                c->cell_first, c->spos, c->smass, c->box, c->terms, n, Dm, c->cfg.theta,
                                c->internal_cap, c->qf, c->aux, c->ctr);
     }
-    // 7. exact bottom-up mass pass (ComputeMass, project.cu:473-502): one launch, see com_up_kernel
+    // 7. exact bottom-up mass pass (ComputeMass, project.cu:473-502): ONE launch for small trees (the climb of
+    //    com_up_kernel), one launch per depth for large ones, where the climb's coherence traffic costs more
+    //    than the launches (measured cross-over ~65k bodies; see com_level_kernel).  Bitwise the same sums.
     if (EXACT && n > 1 && c->internal_cap > 0) {
         const int64_t span = std::min<int64_t>(c->internal_cap, std::max<int64_t>(1, (n - 1) * (int64_t)std::max(1, Dm)));
-        hipLaunchKernelGGL(com_up_kernel, dim3(blocks_for(span, kBlock)), dim3(kBlock), 0, st, c->gd, c->ld,
-                           c->self_node, c->com_pending, c->ctr, c->internal_cap);
+        if (n <= kComClimbMaxBodies) {
+            hipLaunchKernelGGL(com_up_kernel, dim3(blocks_for(span, kBlock)), dim3(kBlock), 0, st, c->gd, c->ld,
+                               c->self_node, c->com_pending, c->ctr, c->internal_cap);
+        } else {
+            for (int d = Dm - 1; d >= 0; --d)
+                hipLaunchKernelGGL(com_level_kernel, dim3(blocks_for(span, kBlock)), dim3(kBlock), 0, st, c->gd,
+                                   c->self_node, c->cell_depth, c->ctr, c->internal_cap, d);
+        }
     }
     BH_HIP(c, hipGetLastError());
     c->tree_valid = true;
@@ -595,7 +606,8 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     A(&c->ctr, 1);
     if (c->exact) {
         A(&c->gd, c->node_cap); A(&c->ld, c->node_cap);
-        A(&c->self_node, c->internal_cap + 1); A(&c->com_pending, c->internal_cap + 1);
+        A(&c->self_node, c->internal_cap + 1); A(&c->com_pending, c->internal_cap + 1); A(&c->cell_depth, c->internal_cap + 1);
+        A(&c->cell_first, c->internal_cap + 1);
     } else {
         A(&c->qf, c->internal_cap + 1); A(&c->aux, 4 * (c->internal_cap + 1));
         A(&c->cell_first, c->internal_cap + 1);

@@ -321,9 +321,8 @@ __global__ __launch_bounds__(kBlock) void scan_apply2(uint32_t *__restrict__ cnt
             cnt[i] = r0;
             // rank -> first body of the cell: lets the node kernel run one thread per CELL (the
             // body that starts a whole chain of nested cells would otherwise process them serially)
-            if (!EXACT)
-                for (uint32_t j = 0; j < v; ++j)
-                    if ((int64_t)(r0 + j) < internal_cap) cell_first[r0 + j] = (uint32_t)i;
+            for (uint32_t j = 0; j < v; ++j)
+                if ((int64_t)(r0 + j) < internal_cap) cell_first[r0 + j] = (uint32_t)i;
         }
         ucarry += utot;
         if (!EXACT) {
@@ -364,22 +363,27 @@ __device__ __forceinline__ int64_t cell_end(const uint64_t *__restrict__ keys, i
     return lower_bound_prefix(keys, a + 1, b, sh, pfx + 1);
 }
 
-// ---- exact-mode nodes kernel: the owner of each subdivided cell writes its four children --------
-// NodeD/LinkD + self_node / pending (subdivided children per cell) for the bottom-up pass.  One thread per sorted neighbour pair;
-// a pair that starts a chain of nested cells handles them in turn (the fp32 kernel below runs one
-// thread per cell instead).  Thread 0 also writes the root when nothing is subdivided (n <= 1 or
-// max_depth == 1).
+// ---- exact-mode nodes kernel: one thread per subdivided cell writes its four children ---------------
+// NodeD/LinkD + self_node / pending (subdivided children per cell) for the bottom-up pass.  Round 1 ran one
+// thread per sorted neighbour pair, and the pair that starts a chain of nested cells handled them in turn:
+// the thread of sorted body 0 walked its whole chain (20 cells whose range searches span the array) while
+// the launch waited -- 2.0 ms at N = 1M.  Now, as in the fp32 kernel, rank r is one thread: its first body
+// comes from cell_first[r], its depth from its position in that body's chain.  Thread 0 also writes the
+// root when nothing is subdivided (n <= 1 or max_depth == 1).  Same arithmetic per cell as before: the box
+// by halving from the root along the key's digits (bitwise the reference's xmin..ymax), depth-cap cells
+// folded in body order (project.cu:360-382).
 __global__ __launch_bounds__(kBlock) void nodes_exact_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm,
-    const uint32_t *__restrict__ off, const double2 *__restrict__ pos, const double *__restrict__ mass,
+    const uint32_t *__restrict__ off, const uint32_t *__restrict__ cell_first,
+    const double2 *__restrict__ pos, const double *__restrict__ mass,
     const double *__restrict__ box, int64_t n, int Dm, int64_t internal_cap, NodeD *__restrict__ gd,
-    LinkD *__restrict__ ld, int32_t *__restrict__ self_node, uint32_t *__restrict__ pending,
-    TreeCounters *ctr)
+    LinkD *__restrict__ ld, int32_t *__restrict__ self_node, int32_t *__restrict__ cell_depth,
+    uint32_t *__restrict__ pending, TreeCounters *ctr)
 {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint32_t total = ctr->n_internal;
 
-    if (i == 0 && total == 0) {
+    if (t == 0 && total == 0) {
         // ---- root only: empty root takes the body (project.cu:398-406) or the root itself is a
         //      depth-cap cell (max_depth == 1, project.cu:360-382)
         double m = 0.0, cx = 0.0, cy = 0.0;
@@ -403,93 +407,80 @@ __global__ __launch_bounds__(kBlock) void nodes_exact_kernel(
         ld[0] = LinkD{-1, occ};
         return;
     }
-
-    if (i + 1 >= n) return;
-    const uint64_t key = keys[i];
-    const int L = shared_levels(key, keys[i + 1], Dm);
-    const int Lp = (i == 0) ? -1 : shared_levels(keys[i - 1], key, Dm);
-    const int dlo = Lp + 1;
-    const int dhi = (L < Dm - 1) ? L : Dm - 1;
-    if (dhi < dlo) return;
     if ((int64_t)total > internal_cap) {
-        if (i == 0) ctr->overflow = 1;
+        if (t == 0) ctr->overflow = 1;
         return;
     }
-    const uint32_t r0 = off[i];
+    if (t >= (int64_t)total) return;
+    const uint32_t r = (uint32_t)t;
+    const int64_t i = (int64_t)cell_first[r];
+    const uint64_t key = keys[i];
+    const int Lp = (i == 0) ? -1 : shared_levels(keys[i - 1], key, Dm);
+    const int d = Lp + 1 + (int)(r - off[i]);               // this cell's depth
 
     double x0 = box[0], x1 = box[1], y0 = box[2], y1 = box[3];
-    for (int l = 0; l < dlo; ++l) {
+    for (int l = 0; l < d; ++l) {
         const int c = (int)((key >> (2 * (Dm - 1 - l))) & 3);
         descend(c, (x0 + x1) / 2, (y0 + y1) / 2, x0, x1, y0, y1);
     }
 
-    int64_t hi = n;
-    for (int d = dlo; d <= dhi; ++d) {
-        const uint32_t r = r0 + (uint32_t)(d - dlo);
-        const int sh = 2 * (Dm - d);                 // bits below the depth-d prefix
-        const uint64_t pfx = (d == 0) ? 0ull : (key >> sh);
-        const int64_t e = (d == 0) ? n : cell_end(keys, i, hi, sh, pfx);
-        hi = e;
-        const int shc = sh - 2;
-        int64_t b[5];
-        b[0] = i; b[4] = e;
-        for (int c = 1; c < 4; ++c) b[c] = lower_bound_prefix(keys, b[c - 1], e, shc, (pfx << 2) | (uint64_t)c);
+    const int sh = 2 * (Dm - d);                     // bits below the depth-d prefix
+    const uint64_t pfx = (d == 0) ? 0ull : (key >> sh);
+    const int64_t e = (d == 0) ? n : cell_end(keys, i, n, sh, pfx);
+    const int shc = sh - 2;
+    int64_t b[5];
+    b[0] = i; b[4] = e;
+    for (int c = 1; c < 4; ++c) b[c] = lower_bound_prefix(keys, b[c - 1], e, shc, (pfx << 2) | (uint64_t)c);
 
-        const double mx = (x0 + x1) / 2.0, my = (y0 + y1) / 2.0;
-        const int32_t quad = 1 + 4 * (int32_t)r;     // id of child 0
+    const double mx = (x0 + x1) / 2.0, my = (y0 + y1) / 2.0;
+    const int32_t quad = 1 + 4 * (int32_t)r;     // id of child 0
 
-        if (d == 0) {                                  // root record (mass/COM come bottom-up)
-            const double ex = x1 - x0, ey = y1 - y0;
-            gd[0].size = (ex > ey) ? ex : ey;
-            ld[0] = LinkD{quad, -1};
-            self_node[0] = 0;
-        }
-        uint32_t n_sub = 0;                            // subdivided children: what the bottom-up pass waits for
-
-        for (int c = 0; c < 4; ++c) {
-            const double cx0 = (c & 1) ? mx : x0, cx1 = (c & 1) ? x1 : mx;
-            const double cy0 = (c & 2) ? my : y0, cy1 = (c & 2) ? y1 : my;
-            const double ex = cx1 - cx0, ey = cy1 - cy0;
-            const double size = (ex > ey) ? ex : ey;
-            const int64_t bc = b[c], nc = b[c + 1] - b[c];
-            const int32_t node = quad + c;
-            double m = 0.0, cx = 0.0, cy = 0.0;
-            int32_t child = -1, occ = -1;
-            if (nc == 0) {
-                // empty leaf: blank child of project.cu:422-428
-            } else if (d + 1 == Dm) {
-                // depth-cap cell, project.cu:360-382: running mean in body order
-                for (int64_t j = bc; j < bc + nc; ++j) {
-                    const uint32_t bi = perm[j];
-                    const double bm = mass[bi], bx = pos[bi].x, by = pos[bi].y;
-                    cx = (m * cx + bm * bx) / (m + bm);
-                    cy = (m * cy + bm * by) / (m + bm);
-                    m += bm;
-                }
-                occ = (nc == 1) ? (-(int32_t)perm[bc] - 2) : -1;
-            } else if (nc == 1) {
-                // single body in an undivided cell, project.cu:398-406
-                const uint32_t bi = perm[bc];
-                m = mass[bi]; cx = pos[bi].x; cy = pos[bi].y;
-                occ = (int32_t)bi;
-            } else {
-                // subdivided cell: its rank follows from its first body and depth
-                const int Lpc = (bc == 0) ? -1 : shared_levels(keys[bc - 1], keys[bc], Dm);
-                const uint32_t rc = off[bc] + (uint32_t)((d + 1) - (Lpc + 1));
-                child = 1 + 4 * (int32_t)rc;
-                self_node[rc] = node;
-                ++n_sub;
-            }
-            gd[node] = NodeD{cx, cy, m, size};
-            ld[node] = LinkD{child, occ};
-        }
-        pending[r] = n_sub;
-        // descend into the child that holds body i (the next cell of this owner's chain)
-        if (d < dhi) {
-            const int c = (int)((key >> (2 * (Dm - 1 - d))) & 3);
-            descend(c, mx, my, x0, x1, y0, y1);
-        }
+    if (d == 0) {                                  // root record (mass/COM come bottom-up)
+        const double ex = x1 - x0, ey = y1 - y0;
+        gd[0].size = (ex > ey) ? ex : ey;
+        ld[0] = LinkD{quad, -1};
+        self_node[0] = 0;
     }
+    cell_depth[r] = d;
+    uint32_t n_sub = 0;                            // subdivided children: what the bottom-up pass waits for
+    for (int c = 0; c < 4; ++c) {
+        const double cx0 = (c & 1) ? mx : x0, cx1 = (c & 1) ? x1 : mx;
+        const double cy0 = (c & 2) ? my : y0, cy1 = (c & 2) ? y1 : my;
+        const double ex = cx1 - cx0, ey = cy1 - cy0;
+        const double size = (ex > ey) ? ex : ey;
+        const int64_t bc = b[c], nc = b[c + 1] - b[c];
+        const int32_t node = quad + c;
+        double m = 0.0, cx = 0.0, cy = 0.0;
+        int32_t child = -1, occ = -1;
+        if (nc == 0) {
+            // empty leaf: blank child of project.cu:422-428
+        } else if (d + 1 == Dm) {
+            // depth-cap cell, project.cu:360-382: running mean in body order
+            for (int64_t j = bc; j < bc + nc; ++j) {
+                const uint32_t bi = perm[j];
+                const double bm = mass[bi], bx = pos[bi].x, by = pos[bi].y;
+                cx = (m * cx + bm * bx) / (m + bm);
+                cy = (m * cy + bm * by) / (m + bm);
+                m += bm;
+            }
+            occ = (nc == 1) ? (-(int32_t)perm[bc] - 2) : -1;
+        } else if (nc == 1) {
+            // single body in an undivided cell, project.cu:398-406
+            const uint32_t bi = perm[bc];
+            m = mass[bi]; cx = pos[bi].x; cy = pos[bi].y;
+            occ = (int32_t)bi;
+        } else {
+            // subdivided cell: its rank follows from its first body and depth
+            const int Lpc = (bc == 0) ? -1 : shared_levels(keys[bc - 1], keys[bc], Dm);
+            const uint32_t rc = off[bc] + (uint32_t)((d + 1) - (Lpc + 1));
+            child = 1 + 4 * (int32_t)rc;
+            self_node[rc] = node;
+            ++n_sub;
+        }
+        gd[node] = NodeD{cx, cy, m, size};
+        ld[node] = LinkD{child, occ};
+    }
+    pending[r] = n_sub;
 }
 
 // ---- fp32 nodes kernel ------------------------------------------------------------------------------
@@ -719,9 +710,9 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     }
 }
 
-// ---- exact bottom-up pass: ComputeMass, project.cu:473-502, ONE launch ---------------------------------
+// ---- exact bottom-up pass: ComputeMass, project.cu:473-502, ONE launch (small trees) -------------------
 // The reference recurses (children before parents).  Round 1 ran one launch per depth (9 at the
-// reference's cap, 31 at cap 32), each ~5 us of launch floor.  Here every thread starts at one subdivided
+// reference's cap, 31 at cap 32), each ~5 us of launch floor -- most of the build at N = 1,024.  Here every thread starts at one subdivided
 // cell; a cell whose four children are all leaves (pending == 0 after the node kernel) is summed at once,
 // and the thread then climbs: it decrements its parent's count of unfinished subdivided children and
 // whoever brings it to zero sums the parent.  Each cell is summed by exactly ONE thread, from the stored
@@ -762,6 +753,33 @@ __global__ __launch_bounds__(kBlock) void com_up_kernel(NodeD *__restrict__ gd, 
         if (left != 1u) break;                        // other subdivided children are still on their way
         r = parent;
     }
+}
+
+// The same pass, one launch per depth (deepest first): what large trees use.  com_up_kernel's agent-scope
+// acquire-release RMW costs a write-back / invalidate of the non-coherent per-XCD L2s per cell: measured
+// 15 us at N = 1,024, 50 us at 65,536 (= nine launches of this kernel), 1.75 ms at N = 1M against ~0.15 ms for
+// twenty launches of this one.  Same sums in the same order either way.
+__global__ __launch_bounds__(kBlock) void com_level_kernel(NodeD *__restrict__ gd, const int32_t *__restrict__ self_node,
+                                                            const int32_t *__restrict__ cell_depth,
+                                                            const TreeCounters *__restrict__ ctr, int64_t internal_cap,
+                                                            int depth)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t total = ctr->n_internal;
+    if (r >= (int64_t)total || (int64_t)total > internal_cap) return;
+    if (cell_depth[r] != depth) return;
+    const int32_t node = self_node[r];
+    const int32_t quad = 1 + 4 * (int32_t)r;
+    double tot = 0.0, sx = 0.0, sy = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const NodeD ch = gd[quad + c];
+        tot += ch.m;
+        sx += ch.m * ch.cx;
+        sy += ch.m * ch.cy;
+    }
+    if (tot > 0.0) { sx /= tot; sy /= tot; }
+    gd[node].cx = sx; gd[node].cy = sy; gd[node].m = tot;
 }
 
 }  // namespace bh
