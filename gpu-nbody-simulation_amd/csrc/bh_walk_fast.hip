@@ -322,6 +322,118 @@ __device__ __forceinline__ uint32_t walk_tree_asm(const QuadF BH_CONSTANT *quads
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35");
     return cost;
 }
+// The same child blocks driven by a LIST of entries instead of the stack: the level-synchronous walk of small
+// launches (SPLIT > 1) hands every wave a chunk of at most 16 frontier entries, lane j of (in_base, in_lo,
+// in_hi) holding entry j.  They are taken in order, two at a time like the stack entries of walk_tree_asm
+// (a bucket reference is served alone), and the children some lane opens are pushed to a fresh stack that
+// starts at entry 0: at most 64 pushes, all in the first register triple.  Returns the number of pushes; the
+// stack itself comes back in (out_base, out_lo, out_hi).  Same operations in the same order as the C++ loop
+// it replaces (bit-identical: test_asm_walk_equals_the_portable_walk, split cases).
+__device__ __forceinline__ int32_t walk_list_asm(const QuadF BH_CONSTANT *quads, const void BH_CONSTANT *consts,
+                                                 int32_t in_base, int32_t in_lo, int32_t in_hi, int32_t mine,
+                                                 float px, float py, float &ax, float &ay, int32_t &out_base,
+                                                 int32_t &out_lo, int32_t &out_hi)
+{
+    int32_t sp;
+    asm volatile(
+        "v_mov_b32_e32 v20, %[px]\n"
+        "v_mov_b32_e32 v21, %[py]\n"
+        "v_mov_b32_e32 v28, %[ax]\n"
+        "v_mov_b32_e32 v29, %[ay]\n"
+        "v_mov_b32_e32 v33, %[ib]\n"
+        "v_mov_b32_e32 v34, %[il]\n"
+        "v_mov_b32_e32 v35, %[ih]\n"
+        "s_mov_b32 m0, 0\n"                                     // pushes so far
+        "s_mov_b32 s72, 0\n"                                    // j: next list entry
+        "Lloop_%=:\n"
+        "s_cmp_ge_u32 s72, %[mine]\n"
+        "s_cbranch_scc1 Ldone_%=\n"
+        "v_readlane_b32 s68, v33, s72\n v_readlane_b32 s44, v34, s72\n v_readlane_b32 s45, v35, s72\n"
+        "s_add_u32 s72, s72, 1\n"
+        "s_cmp_lt_i32 s68, 0\n"
+        "s_cbranch_scc1 Lspecial_%=\n"
+        "s_mov_b32 s71, 0\n"                                    // s71 != 0: a second quad (B) is in flight
+        "s_cmp_ge_u32 s72, %[mine]\n"
+        "s_cbranch_scc1 LloadA_%=\n"
+        "v_readlane_b32 s70, v33, s72\n v_readlane_b32 s46, v34, s72\n v_readlane_b32 s47, v35, s72\n"
+        "s_cmp_lt_i32 s70, 0\n"
+        "s_cbranch_scc1 LloadA_%=\n"                            // a bucket reference: it is served in its own turn
+        "s_add_u32 s72, s72, 1\n"
+        "s_mul_i32 s71, s70, 0x50\n"
+        "s_load_dwordx16 s[48:63], %[quads], s71\n"
+        "s_load_dwordx4 s[64:67], %[quads], s71 offset:0x40\n"
+        "LloadA_%=:\n"
+        "s_mul_i32 s69, s68, 0x50\n"
+        "s_load_dwordx16 s[24:39], %[quads], s69\n"
+        "s_load_dwordx4 s[40:43], %[quads], s69 offset:0x40\n"
+        "s_mov_b64 exec, s[44:45]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        BH_CHILD("s[24:25]", "s32", "s36", "s40", "s[44:45]", "LA0", "")
+        BH_CHILD("s[26:27]", "s33", "s37", "s41", "s[44:45]", "LA1", "")
+        BH_CHILD("s[28:29]", "s34", "s38", "s42", "s[44:45]", "LA2", "")
+        BH_CHILD("s[30:31]", "s35", "s39", "s43", "s[44:45]", "LA3", "")
+        "s_cmp_eq_u32 s71, 0\n"
+        "s_cbranch_scc1 Lloop_%=\n"
+        "s_mov_b64 exec, s[46:47]\n"
+        BH_CHILD("s[48:49]", "s56", "s60", "s64", "s[46:47]", "LB0", "")
+        BH_CHILD("s[50:51]", "s57", "s61", "s65", "s[46:47]", "LB1", "")
+        BH_CHILD("s[52:53]", "s58", "s62", "s66", "s[46:47]", "LB2", "")
+        BH_CHILD("s[54:55]", "s59", "s63", "s67", "s[46:47]", "LB3", "")
+        "s_branch Lloop_%=\n"
+        // ---- bucket reference -(node id) - 2 (see walk_tree_asm); -1 is dropped
+        "Lspecial_%=:\n"
+        "s_cmp_eq_u32 s68, -1\n"
+        "s_cbranch_scc1 Lloop_%=\n"
+        "s_load_dwordx8 s[56:63], %[consts], 0x0\n"
+        "s_sub_i32 s68, -2, s68\n"
+        "s_lshl_b32 s69, s68, 3\n"
+        "s_mov_b64 exec, s[44:45]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_load_dwordx2 s[48:49], s[56:57], s69\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_cmp_lt_i32 s49, 1\n"
+        "s_cbranch_scc1 Lloop_%=\n"
+        "s_add_u32 s49, s48, s49\n"
+        "Lbody_%=:\n"
+        "s_lshl_b32 s69, s48, 3\n"
+        "s_load_dwordx2 s[50:51], s[58:59], s69\n"
+        "s_lshl_b32 s69, s48, 2\n"
+        "s_load_dword s52, s[60:61], s69\n"
+        "s_add_u32 s48, s48, 1\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_pk_add_f32 v[22:23], s[50:51], v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n"
+        "s_cmp_lt_u32 s48, s49\n"
+        "v_mul_f32_e32 v24, v23, v23\n"
+        "v_fmac_f32_e32 v24, v22, v22\n"
+        "v_cmpx_lt_f32_e32 vcc, 0, v24\n"
+        "v_rsq_f32_e32 v25, v24\n"
+        "s_nop 0\n"
+        "v_mul_f32_e32 v26, s52, v25\n"
+        "v_mul_f32_e32 v26, v25, v26\n"
+        "v_mul_f32_e32 v24, v25, v26\n"
+        "v_fmac_f32_e32 v28, v24, v22\n"
+        "v_fmac_f32_e32 v29, v24, v23\n"
+        "s_mov_b64 exec, s[44:45]\n"
+        "s_cbranch_scc1 Lbody_%=\n"
+        "s_branch Lloop_%=\n"
+        "Ldone_%=:\n"
+        "s_mov_b64 exec, -1\n"
+        "s_mov_b32 %[sp], m0\n"
+        "v_mov_b32_e32 %[ax], v28\n"
+        "v_mov_b32_e32 %[ay], v29\n"
+        "v_mov_b32_e32 %[ob], v30\n"
+        "v_mov_b32_e32 %[ol], v31\n"
+        "v_mov_b32_e32 %[oh], v32\n"
+        : [ax] "+v"(ax), [ay] "+v"(ay), [sp] "=&s"(sp), [ob] "=&v"(out_base), [ol] "=&v"(out_lo), [oh] "=&v"(out_hi)
+        : [quads] "s"(quads), [consts] "s"(consts), [px] "v"(px), [py] "v"(py), [ib] "v"(in_base), [il] "v"(in_lo),
+          [ih] "v"(in_hi), [mine] "s"(mine)
+        : "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39",
+          "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+          "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72",
+          "m0", "vcc", "scc", "memory",
+          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35");
+    return sp;
+}
 #undef BH_CHILD
 #undef BH_ITERATION
 
@@ -339,7 +451,7 @@ template <bool LDS_STACK, bool STATS, int MODE, int SPLIT, bool ASM = false>
 __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_kernel(WalkFastArgs a)
 {
     static_assert(SPLIT == 1 || (!LDS_STACK && MODE == 0), "the split walk uses the register-lane stack, loop 0");
-    static_assert(!ASM || (!LDS_STACK && !STATS && MODE == 0 && SPLIT == 1), "the assembly loop is the default one-wave walk");
+    static_assert(!ASM || (!LDS_STACK && !STATS && MODE == 0), "the assembly loops serve the default configuration");
     __shared__ int32_t s_base[LDS_STACK ? kWavesPerBlock : 1][LDS_STACK ? kLdsStackDepth : 1];
     __shared__ uint64_t s_mask[LDS_STACK ? kWavesPerBlock : 1][LDS_STACK ? kLdsStackDepth : 1];
     // split walk: two frontiers (current / next level), the waves' push counts, the partial sums
@@ -542,15 +654,20 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
                     const int32_t b = __builtin_amdgcn_readlane(in_base, j & (kWave - 1));
                     return load_quad(quads + (b < 0 ? 0 : b));
                 };
-                QuadRegs qn = quad_of(0);
-                for (int j = 0; j < mine; ++j) {
-                    int32_t base; uint64_t mask;
-                    lane_entry(in_base, in_lo, in_hi, j, base, mask);
-                    const QuadRegs q = qn;
-                    qn = quad_of(j + 1);
-                    if (base <= -2) { bucket(-base - 2, mask); continue; }
-                    if (base < 0) continue;
-                    eval_quad(q, mask);                         // opened children -> private stack, sp <= 64
+                if (ASM) {
+                    sp = walk_list_asm(quads, as_constant(a.bucket_consts), in_base, in_lo, in_hi, __builtin_amdgcn_readfirstlane(mine), p.x, p.y, ax, ay,
+                                       v_base, v_lo, v_hi);
+                } else {
+                    QuadRegs qn = quad_of(0);
+                    for (int j = 0; j < mine; ++j) {
+                        int32_t base; uint64_t mask;
+                        lane_entry(in_base, in_lo, in_hi, j, base, mask);
+                        const QuadRegs q = qn;
+                        qn = quad_of(j + 1);
+                        if (base <= -2) { bucket(-base - 2, mask); continue; }
+                        if (base < 0) continue;
+                        eval_quad(q, mask);                     // opened children -> private stack, sp <= 64
+                    }
                 }
                 if (lane == 0) f_cnt[w] = sp;
                 __syncthreads();
@@ -793,14 +910,14 @@ static hipError_t launch_mode(const WalkFastArgs &a, int mode, bool xcd, hipStre
     return launch<L, S, 0>(a, xcd, st);
 }
 
-template <bool S>
+template <bool S, bool ASM = false>
 static hipError_t launch_split(const WalkFastArgs &a, int split, bool xcd, hipStream_t st)
 {
     switch (split) {
-    case 2: return launch<false, S, 0, 2>(a, xcd, st);
-    case 4: return launch<false, S, 0, 4>(a, xcd, st);
-    case 8: return launch<false, S, 0, 8>(a, xcd, st);
-    default: return launch<false, S, 0, 16>(a, xcd, st);
+    case 2: return launch<false, S, 0, 2, ASM>(a, xcd, st);
+    case 4: return launch<false, S, 0, 4, ASM>(a, xcd, st);
+    case 8: return launch<false, S, 0, 8, ASM>(a, xcd, st);
+    default: return launch<false, S, 0, 16, ASM>(a, xcd, st);
     }
 }
 
@@ -813,7 +930,8 @@ hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, i
         return launch<false, false, 0, 1, true>(a, xcd, st);
     // the split walk exists for the register-lane stack and loop 0 only; its queue holds 56 roots
     if (split > 1 && !lds_stack && mode == 0 && a.n_trees <= 56)
-        return stats ? launch_split<true>(a, split, xcd, st) : launch_split<false>(a, split, xcd, st);
+        return stats ? launch_split<true>(a, split, xcd, st)
+                     : (use_asm ? launch_split<false, true>(a, split, xcd, st) : launch_split<false>(a, split, xcd, st));
     if (lds_stack) return stats ? launch_mode<true, true>(a, mode, xcd, st) : launch_mode<true, false>(a, mode, xcd, st);
     return stats ? launch_mode<false, true>(a, mode, xcd, st) : launch_mode<false, false>(a, mode, xcd, st);
 }

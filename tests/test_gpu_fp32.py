@@ -114,6 +114,32 @@ def test_asm_walk_equals_the_portable_walk(kind, n, md, compat):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("kind,n,md,compat", [("plummer", 20000, 21, False), ("uniform", 65536, 21, False),
+                                              ("clumped", 30000, 8, False), ("clumped", 30000, 8, True),
+                                              ("plummer", 100000, 21, False), ("uniform", 130, 4, False)])
+def test_asm_list_walk_equals_the_portable_level_walk(kind, n, md, compat):
+    """Small launches walk level by level with several wavefronts per group (8 up to 512 groups, 4 up to
+    1,600); the per-chunk evaluation has the same hand-scheduled child blocks (walk_list_asm).  Bitwise
+    equal to the C++ loop (BH_FLAG_WALK_PORTABLE) -- accelerations and a 3-step trajectory."""
+    if kind == "clumped":
+        rng = np.random.default_rng(5)
+        p = f32(np.concatenate([rng.normal(0, 1e-3, (n // 2, 2)), rng.uniform(-1, 1, (n - n // 2, 2))]))
+        m, v = f32(rng.uniform(0.1, 0.5, n)), f32(rng.uniform(-1e-9, 1e-9, (n, 2)))
+    else:
+        m, p, v = IC.make(kind, n, 3, quasi_static=True)
+    res = []
+    for flags in (0, FLAG_WALK_PORTABLE):
+        with engine(n, max_depth=md, reference_compat=compat, flags=flags) as e:
+            e.upload(p, v, m)
+            e.compute_forces()
+            a = e.accelerations()
+            e.step(3)
+            res.append((a,) + e.download())
+    assert np.isfinite(res[0][0]).all() and np.abs(res[0][0]).max() > 0
+    for x, y in zip(res[0], res[1]):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("kind,n,md", [("plummer", 200000, 21), ("clumped", 30000, 8), ("uniform", 513, 3)])
 def test_packed_sort_equals_the_two_array_sort(monkeypatch, kind, n, md):
     """Keys of <= 40 bits carry the body index in the key word through the radix passes (one 8-byte array per
