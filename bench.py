@@ -366,6 +366,7 @@ def main():
             "minteractions_per_s": ss.interactions * a.steps / elapsed / 1e6,
             "interactions_per_body": ss.interactions / n,
             "build_ms": st.build_ms, "walk_ms": st.walk_ms, "n_nodes": ss.n_nodes,
+            "build_groups_ms": {"keys": st.keys_ms, "sort": st.sort_ms, "scan": st.scan_ms, "nodes": st.nodes_ms},
             "roofline": roof,
         }
         if let_info:

@@ -472,7 +472,10 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
             // (a forest walk keeps the split longer: the level-synchronous walk seeds its first frontier with
             // all the roots, the one-wave loop walks tree after tree -- 8 ranks x 135k bodies: 0.270 vs 0.293 ms;
             // 4 ranks x 268k: 0.346 vs 0.298)
-            split = groups <= 512 ? 8 : groups <= (c->let_mode ? 3072 : 1600) ? 4 : 1;
+            // (measured with the hand-scheduled chunk loop, Plummer, walk ms for split 1 / 2 / 4 / 8 --
+            //  768 groups: .089 .061 .042 .040; 1,536: .094 .073 .059 .074; 2,048: .098 .074 .078 .100;
+            //  3,072: .108 .115 .102 .136; 3,584: .115 .127 .118 .157; profiles/r02_final/split_sweep.txt)
+            split = groups <= (c->let_mode ? 512 : 768) ? 8 : groups <= 3072 ? 4 : 1;
         }
         if (3 * c->Dm + 2 > kWave) split = 1;        // the level-synchronous walk's depth-first fallback has 64 entries
         // hand-scheduled loop: byte offsets into the quad array and the sorted bodies are 32-bit there

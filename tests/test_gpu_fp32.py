@@ -118,8 +118,8 @@ def test_asm_walk_equals_the_portable_walk(kind, n, md, compat):
                                               ("clumped", 30000, 8, False), ("clumped", 30000, 8, True),
                                               ("plummer", 100000, 21, False), ("uniform", 130, 4, False)])
 def test_asm_list_walk_equals_the_portable_level_walk(kind, n, md, compat):
-    """Small launches walk level by level with several wavefronts per group (8 up to 512 groups, 4 up to
-    1,600); the per-chunk evaluation has the same hand-scheduled child blocks (walk_list_asm).  Bitwise
+    """Small launches walk level by level with several wavefronts per group (8 up to 768 groups, 4 up to
+    3,072); the per-chunk evaluation has the same hand-scheduled child blocks (walk_list_asm).  Bitwise
     equal to the C++ loop (BH_FLAG_WALK_PORTABLE) -- accelerations and a 3-step trajectory."""
     if kind == "clumped":
         rng = np.random.default_rng(5)
