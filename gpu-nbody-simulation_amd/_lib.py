@@ -45,6 +45,7 @@ class bh_stats_t(C.Structure):
         ("device_bytes", C.c_uint64),
         ("keys_ms", C.c_double), ("sort_ms", C.c_double), ("scan_ms", C.c_double), ("nodes_ms", C.c_double),
         ("build_bytes", C.c_uint64), ("walk_bytes", C.c_uint64), ("wave_quads", C.c_uint64),
+        ("sort_spill_buckets", C.c_uint64),
     ]
 
 

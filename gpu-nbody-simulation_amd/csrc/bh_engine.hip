@@ -49,6 +49,11 @@ struct bh_ctx {
     int walk_split = 0;            // 0 = automatic
     int walk_mode = 0; bool walk_xcd = false; int walk_order = 0;   // -DBHGPU_EXPERIMENTS builds only (A/B)
     bool walk_asm = true;          // BH_WALK_ASM=0: the C++ loop everywhere (A/B)
+    int sort_bucket = 1;           // 1: bucket sort when the previous build's sorted positions are this body set's
+                                   // (BH_SORT_BUCKET=0: always the LSD passes; 2: always the bucket sort, tests)
+    int64_t samples_n = -1;        // spos holds the sorted positions of a build of this many bodies (-1: none)
+    uint64_t *splitters = nullptr;
+    uint8_t *sort_dig = nullptr;   // bucket of every key (written by the histogram, read by the scatter)
     bool sort_wave_rank = true;    // radix_scatter_w (wave-private ranking); experiments: BH_SORT_WAVE_RANK=0
     int build_items = 0;           // 0 = automatic, else keys per thread in the sort / scan kernels (2, 4, 8)
     bool hilbert = false;                // fp32 mode: Hilbert-ordered keys (BH_HILBERT=0 disables, A/B)  // BH_WALK_PIPE / BH_WALK_XCD override (A/B)
@@ -241,9 +246,14 @@ int enqueue_build_t(bh_ctx *c)
                           && !c->sort_onesweep
 #endif
                           && c->sort_pack;
+        // bucket sort (bh_sort.hpp): one counting pass by splitters from the previous build + one in-LDS sort per bucket
+        bool bucket = false;
+        if constexpr (!EXACT)
+            bucket = pack && n >= 2 && n <= kBucketMaxN && (c->sort_bucket == 2 || (c->sort_bucket == 1 && c->samples_n == n));
         if (pack)
-            hipLaunchKernelGGL((keys_kernel<Real2, true, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
-                               c->box, c->keys[0], c->vals[0], n, Dm);
+            hipLaunchKernelGGL((keys_kernel<Real2, true, true>), dim3(blocks_for(n, kBlock) + (bucket ? 1 : 0)), dim3(kBlock),
+                               0, st, pos, c->box, c->keys[0], c->vals[0], n, Dm,
+                               bucket ? (const float2 *)c->spos : nullptr, c->splitters);
         else if (c->hilbert)
             hipLaunchKernelGGL((keys_kernel<Real2, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
                                c->box, c->keys[0], c->vals[0], n, Dm);
@@ -270,7 +280,17 @@ int enqueue_build_t(bh_ctx *c)
             }
         } else
 #endif
-        if (c->sort_wave_rank) {
+        if (bucket) {
+            constexpr int SI = (ITEMS == kItems ? kSortItems : ITEMS);
+            hipLaunchKernelGGL((radix_hist<SI, 8, true>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->radix_counts, n, 0,
+                               (int)nbl, c->splitters, c->sort_dig);
+            hipLaunchKernelGGL(radix_rowscan, dim3(kBuckets), dim3(kBlock), 0, st, c->radix_counts, c->bsum_sort, (int)nbl);
+            hipLaunchKernelGGL((radix_scatter_w<SI, 8, 1, true>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->vals[0],
+                               c->keys[1], c->vals[1], c->radix_counts, c->bsum_sort, n, 0, (int)nbl, c->sort_dig);
+            hipLaunchKernelGGL(bucket_sort_kernel, dim3(kBuckets), dim3(kBsThreads), 0, st, c->keys[1], c->keys[0], c->vals[0],
+                               c->bsum_sort, &c->ctr->sort_spills);
+            cur = 0;
+        } else if (c->sort_wave_rank) {
             // default: kSortBits-wide digits, wave-private ranking, digit-sorted write-out
             constexpr int SB = kSortBits, SR = 1 << SB, SI = (ITEMS == kItems ? kSortItems : ITEMS);
             const int passes = (2 * Dm + SB - 1) / SB;
@@ -351,6 +371,7 @@ int enqueue_build_t(bh_ctx *c)
         };
         if (ITEMS == kItems && n <= (int64_t)1 << 21) scan_part(std::integral_constant<int, 4>{});
         else scan_part(std::integral_constant<int, ITEMS>{});
+        if constexpr (!EXACT) c->samples_n = n;                  // spos: this build's sorted positions
         if (c->time_groups) (void)hipEventRecord(c->ev_grp[2], st);
     } else {
         c->keys_sorted = c->keys[0];
@@ -557,6 +578,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     if (const char *e = std::getenv("BH_WALK_SPLIT")) c->walk_split = std::atoi(e);
     if (const char *e = std::getenv("BH_WALK_ASM")) c->walk_asm = std::atoi(e) != 0;
     if (const char *e = std::getenv("BH_SORT_PACK")) c->sort_pack = std::atoi(e) != 0;
+    if (const char *e = std::getenv("BH_SORT_BUCKET")) c->sort_bucket = std::atoi(e);
     if (const char *e = std::getenv("BH_BUILD_ITEMS")) c->build_items = std::atoi(e);
     if (const char *e = std::getenv("BH_REORDER_EVERY")) c->reorder_every = std::max(0, std::atoi(e));
     c->hilbert = !c->exact;
@@ -598,6 +620,8 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     { const size_t nbl = std::max<size_t>(blocks_for(cap, kSortTile), blocks_for(std::min<int64_t>(cap, 1 << 22), kBlock * kSmallItems));
       A(&c->radix_counts, (size_t)(1 << kSortBits) * nbl);
       A(&c->bsum_sort, (1 << kSortBits) + 8);
+      A(&c->splitters, kBuckets);
+      if (!c->exact) A(&c->sort_dig, (size_t)std::min<int64_t>(cap, kBucketMaxN) + 16);
 #ifdef BHGPU_EXPERIMENTS
       c->os_status_words = (int64_t)kMaxPasses * nbl * kRadix;
       A(&c->os_status, c->os_status_words); A(&c->os_ghist, kMaxPasses * kRadix); A(&c->os_counter, kMaxPasses);
@@ -699,6 +723,7 @@ int bh_upload(bh_ctx *c, const double *pos, const double *vel, const double *mas
     BH_HIP(c, hipMemset(c->force, 0, std::max<int64_t>(n, 1) * 2 * (c->exact ? sizeof(double) : sizeof(float))));
     c->n = n;
     c->partial_count = 0;
+    c->samples_n = -1;                                        // new bodies: the next build sorts with the LSD passes
     c->uploaded = true;
     c->tree_valid = false;
     c->steps_done = 0;
@@ -760,6 +785,7 @@ int bh_initialize(bh_ctx *c, int64_t n, uint64_t seed, int32_t kind, double lowe
     BH_HIP(c, hipMemsetAsync(c->force, 0, std::max<int64_t>(n, 1) * 2 * (c->exact ? sizeof(double) : sizeof(float)), c->stream));
     c->n = n;
     c->partial_count = 0;
+    c->samples_n = -1;                                        // new bodies: the next build sorts with the LSD passes
     c->uploaded = true;
     c->tree_valid = false;
     c->steps_done = 0;
@@ -1034,6 +1060,11 @@ int bh_stats(bh_ctx *c, bh_stats_t *out)
     out->n_bodies = c->n;
     out->steps_done = c->steps_done;
     out->device_bytes = c->device_bytes;
+    {
+        TreeCounters h{};
+        BH_HIP(c, hipMemcpy(&h, c->ctr, sizeof(h), hipMemcpyDeviceToHost));
+        out->sort_spill_buckets = h.sort_spills;
+    }
     if (c->tree_valid) {
         TreeCounters h{};
         BH_HIP(c, hipMemcpy(&h, c->ctr, sizeof(h), hipMemcpyDeviceToHost));
@@ -1460,6 +1491,7 @@ int bh_migrate_unpack(bh_ctx *c, int64_t n_new)
     }
     c->n = n_new;
     c->partial_count = 0;
+    c->samples_n = -1;                                        // new bodies: the next build sorts with the LSD passes
     c->tree_valid = false;
     c->orig_identity = true;                                // arrival order is the caller order from here on
     c->builds = 0;

@@ -56,20 +56,53 @@ constexpr int kSortBits = 8;
 // ITEMS keys per thread: 8 (tiles of 2,048) when there are enough tiles to fill the GPU, 2 (tiles of
 // 512) for launches of few bodies, where a workgroup's 8 sequential rounds are pure latency.
 // BITS: digit width; counts[digit * nblocks + block].
-template <int ITEMS, int BITS = kRadixBits>
+// ---- bucket sort (launches of up to kBucketMaxN bodies with packed keys) --------------------------------
+// The LSD sort costs five passes of dependent short kernels (~9 us per pass at any size below 1M bodies).
+// Consecutive builds sort almost the same bodies, so the engine sorts in TWO steps instead:
+//   (1) ONE stable counting pass whose "digit" is the bucket of the key among 256 splitters (keys_kernel
+//       derives them from the previous build's sorted positions: near-equal buckets), histogram + row scan
+//       + scatter as for a radix digit;
+//   (2) bucket_sort_kernel: one workgroup per bucket sorts its <= kBucketCap (16,384) keys entirely in LDS (stable
+//       8-bit LSD passes over the key bits that differ inside the bucket) and writes plain keys + indices.
+// The result is the stable sort by key whatever the splitters are -- they only have to be sorted, which
+// keys_kernel guarantees -- so (keys_sorted, perm) is bit-identical to the LSD sort's.  A bucket that does
+// not fit (bodies that moved wildly, a root box that jumped and scrambled the curve) is sorted by its
+// workgroup through global memory: correct, slow, and gone at the next build.
+constexpr int kBuckets = 256;
+static_assert(kBuckets == kBlock, "one thread per bucket / splitter");
+constexpr uint64_t kKeyMask40 = (1ull << 40) - 1;
+// largest j with spl[j] <= key (spl sorted, spl[0] = 0)
+__device__ __forceinline__ uint32_t bucket_of(uint64_t key, const uint64_t *spl)
+{
+    int b = 0;
+#pragma unroll
+    for (int s = kBuckets / 2; s >= 1; s >>= 1) b += (spl[b + s] <= key) ? s : 0;
+    return (uint32_t)b;
+}
+
+// BUCKET: the digit is the key's bucket among the splitters (shift unused)
+template <int ITEMS, int BITS = kRadixBits, bool BUCKET = false>
 __global__ __launch_bounds__(kBlock) void radix_hist(const uint64_t *__restrict__ keys,
                                                       uint32_t *__restrict__ counts, int64_t n,
-                                                      int shift, int nblocks)
+                                                      int shift, int nblocks,
+                                                      const uint64_t *__restrict__ splitters = nullptr,
+                                                      uint8_t *__restrict__ dig8 = nullptr)
 {
     constexpr int R = 1 << BITS;
     __shared__ uint32_t h[R];
+    __shared__ uint64_t spl[BUCKET ? kBuckets : 1];
+    if (BUCKET) spl[threadIdx.x] = splitters[threadIdx.x];
     for (int d = threadIdx.x; d < R; d += kBlock) h[d] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * (kBlock * ITEMS);
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = base + r * kBlock + threadIdx.x;
-        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (R - 1)], 1u);
+        if (i < n) {
+            const uint32_t d = BUCKET ? bucket_of(keys[i] & kKeyMask40, spl) : (uint32_t)(keys[i] >> shift) & (R - 1);
+            if (BUCKET) dig8[i] = (uint8_t)d;                   // the scatter reads it back instead of searching again
+            atomicAdd(&h[d], 1u);
+        }
     }
     __syncthreads();
     for (int d = threadIdx.x; d < R; d += kBlock) counts[(int64_t)d * nblocks + blockIdx.x] = h[d];
@@ -153,15 +186,17 @@ __global__ __launch_bounds__(kBlock) void radix_scatter(const uint64_t *__restri
 // PACK == 2: the last pass, which writes the plain key and the index to their own arrays for the tree build.
 constexpr int kPackShift = 40;
 constexpr uint64_t kPackKeyMask = (1ull << kPackShift) - 1;
-template <int ITEMS, int BITS = kRadixBits, int PACK = 0>
+template <int ITEMS, int BITS = kRadixBits, int PACK = 0, bool BUCKET = false>
 __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__restrict__ kin,
                                                            const uint32_t *__restrict__ vin,
                                                            uint64_t *__restrict__ kout,
                                                            uint32_t *__restrict__ vout,
                                                            const uint32_t *__restrict__ offs,
                                                            const uint32_t *__restrict__ row_total, int64_t n,
-                                                           int shift, int nblocks)
+                                                           int shift, int nblocks,
+                                                           const uint8_t *__restrict__ dig8 = nullptr)
 {
+    static_assert(!BUCKET || (PACK == 1 && BITS == 8), "the bucket pass moves packed keys");
     // (4) the tile is first sorted by digit INTO LDS, then written out in that order: the keys a digit
     // has in a tile leave as one contiguous run instead of separate partial-line writes from
     // different rounds
@@ -173,6 +208,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
     __shared__ uint64_t skey[TILE];
     __shared__ uint32_t sval[PACK ? 1 : TILE];
     __shared__ uint32_t sm[kWavesPerBlock + 1];
+    __shared__ uint8_t sdig[BUCKET ? TILE : 1];             // BUCKET: the bucket of every key of the sorted tile
     const int t = threadIdx.x, w = wave_id(), l = lane_id();
     for (int d = t; d < R; d += kBlock)
 #pragma unroll
@@ -183,13 +219,15 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
     const int64_t base = tile_base + (int64_t)w * (kWave * ITEMS);
     uint64_t key[ITEMS];
     uint32_t val[PACK ? 1 : ITEMS];
+    uint32_t dig[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = base + r * kWave + l;
         const bool valid = i < n;
         key[r] = valid ? kin[i] : ~0ull;
         if (!PACK) val[r] = valid ? vin[i] : 0u;
-        if (valid) atomicAdd(&woff[w][(uint32_t)(key[r] >> shift) & (R - 1)], 1u);
+        dig[r] = BUCKET ? (valid ? (uint32_t)dig8[i] : 0u) : (uint32_t)(key[r] >> shift) & (R - 1);
+        if (valid) atomicAdd(&woff[w][dig[r]], 1u);
     }
     __syncthreads();
     {
@@ -225,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
     for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = base + r * kWave + l;
         const bool valid = i < n;
-        const uint32_t d = (uint32_t)(key[r] >> shift) & (R - 1);
+        const uint32_t d = dig[r];
         uint64_t peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < BITS; ++b) {
@@ -239,6 +277,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
         if (valid) {
             skey[o + rank] = key[r];
             if (!PACK) sval[o + rank] = val[r];
+            if (BUCKET) sdig[o + rank] = (uint8_t)d;
         }
         if (valid && rank == 0) woff[w][d] = o + (uint32_t)__popcll(peers);   // ... before its leader advances it
     }
@@ -250,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
         const int lp = r * kBlock + t;
         if (lp < count) {
             const uint64_t k = skey[lp];
-            const int64_t dst = (int64_t)lp + gdelta[(uint32_t)(k >> shift) & (R - 1)];
+            const int64_t dst = (int64_t)lp + gdelta[BUCKET ? (uint32_t)sdig[lp] : (uint32_t)(k >> shift) & (R - 1)];
             if (PACK == 2) {
                 kout[dst] = k & kPackKeyMask;
                 vout[dst] = (uint32_t)(k >> kPackShift);
@@ -259,6 +298,225 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
                 if (!PACK) vout[dst] = sval[lp];
             }
         }
+    }
+}
+
+// ---- step (2) of the bucket sort ------------------------------------------------------------------------
+// (A root box that moves by a depth-12 cell width per step re-aligns every finer cell, so in a dense core --
+// where a bucket is a few such cells -- the re-keyed splitters are only as good as random ones at that scale:
+// the largest of 256 buckets was 1.5x the average on the dynamic Plummer workload at N = 1.1M.  The LDS
+// buffer therefore holds twice the average bucket of the largest launch, four times that of N = 1M.)
+constexpr int kBsThreads = 1024, kBsWaves = kBsThreads / kWave;   // 16 waves: 4 per SIMD hide the LDS round trips
+constexpr int kBucketItemsMax = 16;
+constexpr int kBucketCap = kBucketItemsMax * kBsThreads;      // 16,384 keys (128 of the CU's 160 KB of LDS)
+constexpr int64_t kBucketMaxN = (int64_t)kBuckets * (kBucketCap / 2);       // 2,097,152 bodies
+
+// exclusive scan of the 256 values held by threads 0..255 of the 1,024-thread workgroup (every thread calls;
+// threads 256.. pass 0 and ignore the result)
+__device__ __forceinline__ uint32_t bs_scan256(uint32_t v, uint32_t *sm, uint32_t &total)
+{
+    const int w = wave_id();
+    const uint32_t inc = wave_inclusive_sum(v);
+    if (w < 4 && lane_id() == kWave - 1) sm[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint32_t q = sm[k]; base += (k < w) ? q : 0u; tot += q; }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+// m <= 1,024 * ITEMS keys of one bucket: stable LSD passes over the low `passes` bytes, keys in registers
+// between passes (wave w owns the contiguous keys [w * 64 * ITEMS, ...) as in radix_scatter_w), ranks by
+// ballot matching, one LDS buffer.
+template <int ITEMS>
+__device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in, int m, int passes,
+                                                uint64_t *skey, uint32_t (*woff)[kBuckets], uint32_t *sm,
+                                                uint64_t *__restrict__ kout, uint32_t *__restrict__ vout)
+{
+    const int t = threadIdx.x, w = wave_id(), l = lane_id();
+    const int wbase = w * (kWave * ITEMS);
+    uint64_t key[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int i = wbase + r * kWave + l;
+        key[r] = (i < m) ? in[i] : ~0ull;
+    }
+    if (passes == 0) {                                          // all keys equal (or one key): order is final
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const int i = wbase + r * kWave + l;
+            if (i < m) { kout[i] = key[r] & kKeyMask40; vout[i] = (uint32_t)(key[r] >> kPackShift); }
+        }
+        return;
+    }
+    const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * p;
+        for (int k = t; k < kBsWaves * kBuckets; k += kBsThreads) (&woff[0][0])[k] = 0;
+        __syncthreads();                                        // (also: last pass's reads of skey are done)
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const int i = wbase + r * kWave + l;
+            if (i < m) atomicAdd(&woff[w][(uint32_t)(key[r] >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        {
+            uint32_t c = 0;
+            if (t < kBuckets) {
+#pragma unroll
+                for (int k = 0; k < kBsWaves; ++k) c += woff[k][t];
+            }
+            uint32_t all;
+            uint32_t run = bs_scan256(c, sm, all);
+            if (t < kBuckets) {
+#pragma unroll
+                for (int k = 0; k < kBsWaves; ++k) { const uint32_t cc = woff[k][t]; woff[k][t] = run; run += cc; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const int i = wbase + r * kWave + l;
+            const bool valid = i < m;
+            const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+            uint64_t peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                peers &= bit ? bal : ~bal;
+            }
+            const uint32_t rank = __popcll(peers & lt);
+            uint32_t o = 0;
+            if (valid) o = woff[w][d];
+            if (valid) skey[o + rank] = key[r];
+            if (valid && rank == 0) woff[w][d] = o + (uint32_t)__popcll(peers);
+        }
+        __syncthreads();
+        if (p + 1 < passes) {
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) {
+                const int i = wbase + r * kWave + l;
+                key[r] = (i < m) ? skey[i] : ~0ull;
+            }
+        }
+    }
+    for (int i = t; i < m; i += kBsThreads) {
+        const uint64_t k = skey[i];
+        kout[i] = k & kKeyMask40;
+        vout[i] = (uint32_t)(k >> kPackShift);
+    }
+}
+
+// One workgroup of 1,024 threads per bucket.  bucketed: the packed keys grouped by bucket (step 1's output);
+// kout / vout: the sorted plain keys and body indices; kout doubles as the second buffer of the
+// through-memory path.
+__global__ __launch_bounds__(kBsThreads) void bucket_sort_kernel(uint64_t *__restrict__ bucketed,
+                                                                  uint64_t *__restrict__ kout,
+                                                                  uint32_t *__restrict__ vout,
+                                                                  const uint32_t *__restrict__ bucket_total,
+                                                                  uint32_t *__restrict__ spills)
+{
+    __shared__ uint64_t skey[kBucketCap];
+    __shared__ uint32_t woff[kBsWaves][kBuckets];
+    __shared__ uint32_t sm[8];
+    __shared__ uint64_t s_or[kBsWaves];
+    __shared__ uint32_t s_start, s_m;
+    const int t = threadIdx.x, w = wave_id(), l = lane_id();
+    {
+        const uint32_t mine = (t < kBuckets) ? bucket_total[t] : 0u;
+        uint32_t all;
+        const uint32_t ex = bs_scan256(mine, sm, all);
+        if (t == (int)blockIdx.x) { s_start = ex; s_m = mine; }
+        __syncthreads();
+    }
+    const int64_t start = s_start;
+    const int m = (int)s_m;
+    if (m == 0) return;
+    uint64_t *in = bucketed + start;
+    uint64_t *ko = kout + start;
+    uint32_t *vo = vout + start;
+
+    // which key bits differ inside the bucket: only those bytes need a pass
+    const uint64_t k0 = in[0];
+    uint64_t x = 0;
+    for (int i = t; i < m; i += kBsThreads) x |= (in[i] ^ k0) & kKeyMask40;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x |= __shfl_xor(x, o);
+    if (l == 0) s_or[w] = x;
+    __syncthreads();
+    x = 0;
+#pragma unroll
+    for (int k = 0; k < kBsWaves; ++k) x |= s_or[k];
+    const int passes = x ? (64 - __clzll(x) + 7) / 8 : 0;
+
+    if (m <= 1 * kBsThreads) { bucket_sort_lds<1>(in, m, passes, skey, woff, sm, ko, vo); return; }
+    if (m <= 2 * kBsThreads) { bucket_sort_lds<2>(in, m, passes, skey, woff, sm, ko, vo); return; }
+    if (m <= 4 * kBsThreads) { bucket_sort_lds<4>(in, m, passes, skey, woff, sm, ko, vo); return; }
+    if (m <= 6 * kBsThreads) { bucket_sort_lds<6>(in, m, passes, skey, woff, sm, ko, vo); return; }
+    if (m <= 8 * kBsThreads) { bucket_sort_lds<8>(in, m, passes, skey, woff, sm, ko, vo); return; }
+    if (m <= kBucketCap) { bucket_sort_lds<kBucketItemsMax>(in, m, passes, skey, woff, sm, ko, vo); return; }
+
+    // ---- the bucket does not fit: the same stable passes through global memory, 1,024 keys per round, by this
+    // workgroup alone (all its waves share one L1: workgroup barriers order the stores and the loads)
+    if (t == 0) atomicAdd(spills, 1u);
+    uint64_t *src = in, *dst = ko;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(skey);        // [256] counts, then running bases
+    const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * p;
+        if (t < kBuckets) hist[t] = 0;
+        for (int k = t; k < kBsWaves * kBuckets; k += kBsThreads) (&woff[0][0])[k] = 0;
+        __syncthreads();
+        for (int i = t; i < m; i += kBsThreads) atomicAdd(&hist[(uint32_t)(src[i] >> shift) & 255u], 1u);
+        __syncthreads();
+        {
+            const uint32_t c = (t < kBuckets) ? hist[t] : 0u;
+            uint32_t all;
+            const uint32_t e = bs_scan256(c, sm, all);
+            if (t < kBuckets) hist[t] = e;
+        }
+        __syncthreads();
+        for (int i0 = 0; i0 < m; i0 += kBsThreads) {
+            const int i = i0 + t;
+            const bool valid = i < m;
+            const uint64_t key = valid ? src[i] : ~0ull;
+            const uint32_t d = (uint32_t)(key >> shift) & 255u;
+            uint64_t peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                peers &= bit ? bal : ~bal;
+            }
+            const uint32_t rank = __popcll(peers & lt);
+            if (valid && rank == 0) woff[w][d] = (uint32_t)__popcll(peers);
+            __syncthreads();
+            if (valid) {
+                uint32_t o = hist[d] + rank;
+                for (int k = 0; k < w; ++k) o += woff[k][d];
+                dst[o] = key;
+            }
+            __syncthreads();
+            if (t < kBuckets) {
+                uint32_t sacc = 0;
+#pragma unroll
+                for (int k = 0; k < kBsWaves; ++k) { sacc += woff[k][t]; woff[k][t] = 0; }
+                hist[t] += sacc;
+            }
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+        uint64_t *tmp = src; src = dst; dst = tmp;
+    }
+    // unpack where the keys ended up (element-wise, so doing it in place in kout is safe)
+    for (int i = t; i < m; i += kBsThreads) {
+        const uint64_t k = src[i];
+        ko[i] = k & kKeyMask40;
+        vo[i] = (uint32_t)(k >> kPackShift);
     }
 }
 

@@ -130,23 +130,16 @@ __host__ __device__ __forceinline__ int hilbert_next(int state, int c) { return 
 // change.  64 consecutive bodies then form a more compact patch, and a wavefront touches ~7 %
 // fewer distinct nodes (measured with the oracle: U64 13.99 -> 13.08 Plummer, 10.79 -> 9.97
 // uniform).  Exact mode keeps child-index order (the reference's depth-cap fold follows it).
-// PACK: the body index is written into bits 40..63 of the key word instead of the index array (bh_sort.hpp)
-template <typename Real2, bool HILBERT, bool PACK = false>
-__global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ pos,
-                                                       const double *__restrict__ box,
-                                                       uint64_t *__restrict__ keys,
-                                                       uint32_t *__restrict__ idx, int64_t n, int Dm)
+//
+// DetermineChild with two compares instead of four -- !(x < mx) is (x >= mx) -- as long as every
+// compare is ordered: finite body, finite box.  Anything else (a body at infinity blows the box up,
+// NaN coordinates) takes the reference's four tests, which send unordered compares to child 3 and so
+// collapse such bodies into one cell instead of spreading them over a tree of their own.
+template <bool HILBERT>
+__device__ __forceinline__ uint64_t key_of(double x, double y, double x0, double x1, double y0, double y1, int Dm)
 {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const double x = (double)pos[i].x, y = (double)pos[i].y;
-    double x0 = box[0], x1 = box[1], y0 = box[2], y1 = box[3];
     uint64_t k = 0;
     int state = 0;
-    // DetermineChild with two compares instead of four -- !(x < mx) is (x >= mx) -- as long as every
-    // compare is ordered: finite body, finite box.  Anything else (a body at infinity blows the box up,
-    // NaN coordinates) takes the reference's four tests, which send unordered compares to child 3 and so
-    // collapse such bodies into one cell instead of spreading them over a tree of their own.
     const bool ordered = HILBERT && isfinite(x) && isfinite(y) && isfinite(x0) && isfinite(x1) && isfinite(y0) &&
                          isfinite(y1);
     if (ordered) {
@@ -172,6 +165,55 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
             descend(c, mx, my, x0, x1, y0, y1);
         }
     }
+    return k;
+}
+
+// PACK: the body index is written into bits 40..63 of the key word instead of the index array (bh_sort.hpp).
+// samples != nullptr (bucket sort, bh_sort.hpp): workgroup 0 also produces the 256 splitters of this build --
+// the keys, in THIS build's box, of the positions that stood at the ranks j * n / 256 of the previous build's
+// sorted order, sorted (rank by counting; splitter 0 is 0).  Bodies move little between two builds, so
+// the splitters cut the new keys into near-equal buckets, whatever happened to the root box in between.
+template <typename Real2, bool HILBERT, bool PACK = false>
+__global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ pos,
+                                                       const double *__restrict__ box,
+                                                       uint64_t *__restrict__ keys,
+                                                       uint32_t *__restrict__ idx, int64_t n, int Dm,
+                                                       const float2 *__restrict__ samples = nullptr,
+                                                       uint64_t *__restrict__ splitters = nullptr)
+{
+    const double x0 = box[0], x1 = box[1], y0 = box[2], y1 = box[3];
+    if (samples != nullptr && blockIdx.x == 0) {                // one extra workgroup (the grid is one larger)
+        __shared__ uint64_t sk[kBlock];
+        const int t = threadIdx.x;
+        uint64_t mine = 0;
+        if (t > 0) {
+            // the sample's cell by one multiply per axis -- not the exact bisection: a splitter does not have
+            // to be the key of anything, the 256 of them only have to be sorted -- then the curve digits
+            const float2 q = samples[(int64_t)t * n / kBlock];
+            const double side = (double)(1u << Dm), top = side - 1.0;
+            const double fx = fmin(fmax(((double)q.x - x0) / (x1 - x0) * side, 0.0), top);
+            const double fy = fmin(fmax(((double)q.y - y0) / (y1 - y0) * side, 0.0), top);
+            const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+            int state = 0;
+            for (int l = Dm - 1; l >= 0; --l) {
+                const int cc = (int)(((ix >> l) & 1u) | (((iy >> l) & 1u) << 1));
+                mine = (mine << 2) | (uint64_t)(HILBERT ? hilbert_digit(state, cc) : cc);
+                state = hilbert_next(state, cc);
+            }
+        }
+        // rank by counting; the thread index in the low byte makes the 256 values distinct (one compare each)
+        const uint64_t tagged = (mine << 8) | (uint64_t)t;
+        sk[t] = tagged;
+        __syncthreads();
+        int rank = 0;
+#pragma unroll 16
+        for (int j = 0; j < kBlock; ++j) rank += (sk[j] < tagged) ? 1 : 0;
+        splitters[rank] = mine;
+        return;
+    }
+    const int64_t i = ((int64_t)blockIdx.x - (samples != nullptr ? 1 : 0)) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = key_of<HILBERT>((double)pos[i].x, (double)pos[i].y, x0, x1, y0, y1, Dm);
     if (PACK) {
         keys[i] = k | ((uint64_t)i << kPackShift);
     } else {

@@ -71,6 +71,7 @@ class BhStats:
     build_bytes: int = 0        # algorithmic bytes of that step
     walk_bytes: int = 0
     wave_quads: int = 0         # FLAG_WALK_STATS: quads loaded, once per wavefront
+    sort_spill_buckets: int = 0  # bucket-sort buckets sorted through memory since creation (0 in steady motion)
 
 
 def _dptr(a: np.ndarray):
@@ -191,7 +192,7 @@ class BarnesHutEngine:
         self._check(self._lib.bh_stats(self._h, C.byref(s)))
         return BhStats(s.n_bodies, s.n_nodes, s.n_internal, s.steps_done, s.visits, s.interactions,
                        s.wave_nodes, s.last_step_ms, s.build_ms, s.walk_ms, s.device_bytes, s.keys_ms, s.sort_ms,
-                       s.scan_ms, s.nodes_ms, s.build_bytes, s.walk_bytes, s.wave_quads)
+                       s.scan_ms, s.nodes_ms, s.build_bytes, s.walk_bytes, s.wave_quads, s.sort_spill_buckets)
 
     # -- multi-GPU plumbing -----------------------------------------------------------------
     def set_owned_fraction(self, rank: int, world: int) -> None:

@@ -130,6 +130,8 @@ typedef struct bh_stats_t {
                                     wavefront evaluates (needs BH_FLAG_WALK_STATS, else 0)    */
     uint64_t wave_quads;         /* BH_FLAG_WALK_STATS: sibling quads loaded, counted once per
                                     wavefront (the walk's memory round trips)                 */
+    uint64_t sort_spill_buckets; /* buckets of the bucket sort that did not fit on chip and were sorted
+                                    through memory, since bh_create (0 in steady motion)      */
 } bh_stats_t;
 
 typedef struct bh_ctx bh_ctx;

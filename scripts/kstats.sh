@@ -1,10 +1,11 @@
 #!/bin/bash
-# per-kernel average durations (rocprofv3 --kernel-trace --stats) of a bench run: scripts/kstats.sh <tag> [bench args]
+# per-kernel average durations (rocprofv3 --kernel-trace --stats) of a run: scripts/kstats.sh <tag> <script.py> [args]
 TAG=$1; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-secondary "$@" > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 "$@" > $OUT/trace.log 2>&1
+tail -1 $OUT/trace.log
 python3 - <<PY
 import csv,glob
 f=glob.glob("$OUT/trace/**/*kernel_stats.csv",recursive=True)[0]

@@ -165,6 +165,73 @@ def test_packed_sort_equals_the_two_array_sort(monkeypatch, kind, n, md):
         assert np.array_equal(x, y)
 
 
+def _sort_case(kind, n):
+    if kind == "clumped":
+        rng = np.random.default_rng(5)
+        p = f32(np.concatenate([rng.normal(0, 1e-3, (n // 2, 2)), rng.uniform(-1, 1, (n - n // 2, 2))]))
+        return f32(rng.uniform(0.1, 0.5, n)), p, f32(rng.normal(0, 1e-4, (n, 2)))
+    return IC.make(kind, n, 3, quasi_static=True, drift_cells=1.0)
+
+
+@pytest.mark.parametrize("kind,n,md,precision", [("plummer", 200000, 21, "f32"), ("clumped", 30000, 8, "f32"),
+                                                  ("uniform", 513, 3, "f32"), ("uniform", 2, 5, "f32"),
+                                                  ("plummer", 1100000, 21, "f32"), ("uniform", 70000, 21, "mixed"),
+                                                  ("clumped", 60000, 21, "f32")])
+def test_bucket_sort_equals_the_lsd_sort(monkeypatch, kind, n, md, precision):
+    """From the second build on the keys are sorted by ONE counting pass over 256 buckets -- splitters = the
+    previous build's sorted positions at every n/256-th rank, re-keyed in the new root box -- and an in-LDS
+    sort of every bucket (BH_SORT_BUCKET=0: the five LSD passes every time).  Same stable order: the tree of
+    a later build and a moving trajectory are BITWISE the same, including bodies that share a depth-cap
+    cell (equal keys keep body order) and buckets of equal keys larger than the LDS capacity."""
+    m, p, v = _sort_case(kind, n)
+    prec = {"f32": G.Precision.F32, "mixed": G.Precision.MIXED}[precision]
+    res, spills = [], []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BH_SORT_BUCKET", mode)
+        with engine(n, max_depth=md, reference_compat=False, precision=prec) as e:
+            e.upload(p, v, m)
+            e.step(3)
+            e.build_tree()                                         # (mode 1: a bucket-sorted build)
+            nodes, depth = e.export_tree()
+            e.step(18)                                             # crosses a re-ordering of the state (every 16th build)
+            res.append((nodes, depth) + e.download())
+            spills.append(e.stats().sort_spill_buckets)
+    for x, y in zip(res[0], res[1]):
+        assert np.array_equal(x, y)
+    assert spills[1] == 0
+    if kind != "clumped":
+        assert spills[0] == 0                                      # steady motion: every bucket fits on chip
+
+
+def test_bucket_sort_with_useless_splitters_spills_and_stays_correct(monkeypatch):
+    """BH_SORT_BUCKET=2 takes the splitters from whatever the last build left behind even after bh_upload
+    replaced the bodies: a uniform box first, then a tight clump with two far bodies -- nearly all keys fall
+    into a few buckets, which their workgroups sort through memory.  The order is still the LSD sort's."""
+    n = 50000
+    m1, p1, v1 = IC.make("uniform", n, 9, quasi_static=True)
+    rng = np.random.default_rng(11)
+    p2 = f32(np.concatenate([rng.normal(0.3, 2e-3, (n - 2, 2)), [[-1.0, -1.0], [1.0, 1.0]]]))
+    v2 = f32(rng.normal(0, 1e-5, (n, 2)))
+    res = []
+    for mode in ("2", "0"):
+        monkeypatch.setenv("BH_SORT_BUCKET", mode)
+        with engine(n, max_depth=21, reference_compat=False) as e:
+            e.upload(p1, v1, m1)
+            e.step(2)
+            before = e.stats().sort_spill_buckets
+            e.upload(p2, v2, m1)
+            e.build_tree()
+            nodes, depth = e.export_tree()
+            spilled = e.stats().sort_spill_buckets - before
+            e.step(5)
+            res.append((nodes, depth) + e.download())
+            if mode == "2":
+                assert spilled >= 1
+                assert e.stats().sort_spill_buckets - before == spilled   # the next builds are balanced again
+    for x, y in zip(res[0], res[1]):
+        assert np.array_equal(x, y)
+
+
 def test_multistep_trajectory_encounter_free_case(gold):
     """20 steps vs the REFERENCE's own trajectory (golden; encounter-free by construction, see
     scripts/make_golden.py): positions <= 1e-6 x box width; the velocity CHANGE (what the forces did)
