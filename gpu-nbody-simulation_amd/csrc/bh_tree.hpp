@@ -27,6 +27,8 @@
 // (it was 40).
 #pragma once
 
+#include <type_traits>
+
 #include "bh_prims.hpp"
 #include "bh_sort.hpp"
 #include "bh_nodes.hpp"
@@ -622,19 +624,82 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
         return (k >= 0 && k < kKeyWin) ? wkeys[k] : keys[j];
     };
 
-    // first j in [lo, hi) with (key_j >> sh) >= target.  Large ranges are narrowed on the sampled
-    // index first: after that the remaining range is < 2*kCoarse wide.
-    auto lower_bound = [&](int32_t lo, int32_t hi, int sh, uint64_t target) -> int32_t {
-        if (hi - lo > 4 * kCoarse) {
-            int32_t cl = (lo + kCoarse - 1) / kCoarse, ch = (hi - 1) / kCoarse + 1;   // samples inside [lo, hi)
-            // first sample index c in [cl, ch) with (coarse[c] >> sh) >= target
-            while (cl < ch) { const int32_t mid = (int32_t)(((uint32_t)cl + (uint32_t)ch) >> 1); if ((coarse[mid] >> sh) < target) cl = mid + 1; else ch = mid; }
-            const int32_t up = (cl * kCoarse < hi) ? cl * kCoarse : hi;              // key[up] >= target (or up == hi)
-            const int32_t dn = ((cl - 1) * kCoarse > lo) ? (cl - 1) * kCoarse : lo;  // key[dn] < target (or dn == lo)
-            lo = dn; hi = up;
+    // first j in [lo, hi) with (key_j >> sh) >= target, for NT ascending targets at once.  The kernel's time
+    // is the longest chain of DEPENDENT loads of any thread -- the few large cells near the root search
+    // ranges of 10^5 keys through L2 -- so every round probes the three quartile points of every search
+    // together (3 * NT independent loads in flight, log4 instead of log2 rounds; round 1's one-probe
+    // bisection of the end and of the three child boundaries one after the other was a chain of ~80 loads).
+    // Large ranges are narrowed on the sampled index first: after that the range is < 2*kCoarse wide.
+    auto search = [&](auto nt_tag, int32_t lo0, int32_t hi0, int sh, const uint64_t *target, int32_t *res) {
+        constexpr int NT = decltype(nt_tag)::value;
+        int32_t lo[NT], hi[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) { lo[c] = lo0; hi[c] = hi0; }
+        if (hi0 - lo0 > 4 * kCoarse) {
+            // first sample index s in [cl, ch) with (coarse[s] >> sh) >= target
+            int32_t cl[NT], ch[NT];
+            bool more = true;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) { cl[c] = (lo0 + kCoarse - 1) / kCoarse; ch[c] = (hi0 - 1) / kCoarse + 1; }
+            while (more) {
+                uint64_t k1[NT], k2[NT], k3[NT];
+                int32_t p1[NT], p2[NT], p3[NT];
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+                    const int32_t len = ch[c] - cl[c];
+                    p1[c] = cl[c] + len / 4; p2[c] = cl[c] + len / 2; p3[c] = cl[c] + (int32_t)((3 * (int64_t)len) / 4);
+                    const bool on = len > 0;
+                    k1[c] = on ? coarse[p1[c]] : 0ull; k2[c] = on ? coarse[p2[c]] : 0ull; k3[c] = on ? coarse[p3[c]] : 0ull;
+                }
+                more = false;
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+                    if (ch[c] - cl[c] > 0) {
+                        if ((k1[c] >> sh) >= target[c]) ch[c] = p1[c];
+                        else if ((k2[c] >> sh) >= target[c]) { cl[c] = p1[c] + 1; ch[c] = p2[c]; }
+                        else if ((k3[c] >> sh) >= target[c]) { cl[c] = p2[c] + 1; ch[c] = p3[c]; }
+                        else cl[c] = p3[c] + 1;
+                    }
+                    more = more || (ch[c] - cl[c] > 0);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                const int32_t up = (cl[c] * kCoarse < hi0) ? cl[c] * kCoarse : hi0;             // key[up] >= target (or up == hi)
+                const int32_t dn = ((cl[c] - 1) * kCoarse > lo0) ? (cl[c] - 1) * kCoarse : lo0; // key[dn] < target (or dn == lo)
+                lo[c] = dn; hi[c] = up;
+            }
         }
-        while (lo < hi) { const int32_t mid = (int32_t)(((uint32_t)lo + (uint32_t)hi) >> 1); if ((K(mid) >> sh) < target) lo = mid + 1; else hi = mid; }
-        return lo;
+        bool more = true;
+        while (more) {
+            uint64_t k1[NT], k2[NT], k3[NT];
+            int32_t p1[NT], p2[NT], p3[NT];
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                const int32_t len = hi[c] - lo[c];
+                p1[c] = lo[c] + len / 4; p2[c] = lo[c] + len / 2; p3[c] = lo[c] + (int32_t)((3 * (int64_t)len) / 4);
+                const bool on = len > 0;
+                k1[c] = on ? K(p1[c]) : 0ull; k2[c] = on ? K(p2[c]) : 0ull; k3[c] = on ? K(p3[c]) : 0ull;
+            }
+            more = false;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                if (hi[c] - lo[c] > 0) {
+                    if ((k1[c] >> sh) >= target[c]) hi[c] = p1[c];
+                    else if ((k2[c] >> sh) >= target[c]) { lo[c] = p1[c] + 1; hi[c] = p2[c]; }
+                    else if ((k3[c] >> sh) >= target[c]) { lo[c] = p2[c] + 1; hi[c] = p3[c]; }
+                    else lo[c] = p3[c] + 1;
+                }
+                more = more || (hi[c] - lo[c] > 0);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) res[c] = lo[c];
+    };
+    auto lower_bound = [&](int32_t lo, int32_t hi, int sh, uint64_t target) -> int32_t {
+        int32_t r;
+        search(std::integral_constant<int, 1>{}, lo, hi, sh, &target, &r);
+        return r;
     };
 
     float res_cx[4], res_cy[4], res_m[4], res_thr[4];
@@ -652,7 +717,13 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     const int sh = 2 * (Dm - d);
     const uint64_t pfx = (d == 0) ? 0ull : (key >> sh);
     int32_t e;
+#if defined(BHGPU_EXPERIMENTS) && defined(BH_NODES_EXPT)
+    const bool expt_skip = d < BH_NODES_EXPT;                   // timing experiment: cells above this depth skip their searches
+#else
+    constexpr bool expt_skip = false;
+#endif
     if (d == 0) e = n;
+    else if (expt_skip) e = i + 1;
     else {                                                       // galloping, then bisection
         int32_t a = i + 1, step = 1, b;
         for (;;) {
@@ -685,7 +756,11 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     // dependent memory accesses (3 rounds of resident workgroups x one chain at N = 1M)
     int32_t bnd[5];
     bnd[0] = i; bnd[4] = e;
-    for (int c = 1; c < 4; ++c) bnd[c] = lower_bound(bnd[c - 1], e, shc, (pfx << 2) | (uint64_t)c);
+    {
+        const uint64_t tg[3] = {(pfx << 2) | 1ull, (pfx << 2) | 2ull, (pfx << 2) | 3ull};
+        if (!expt_skip) search(std::integral_constant<int, 3>{}, i, e, shc, tg, &bnd[1]);
+        else bnd[1] = bnd[2] = bnd[3] = e;
+    }
     d3 ps[5];
     uint32_t offc[4];
     uint64_t kprev[4], kcur[4];
