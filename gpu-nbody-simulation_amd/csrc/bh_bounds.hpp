@@ -26,4 +26,23 @@ __device__ __forceinline__ void block_bounds_to_partial(bool valid, double x, do
     }
 }
 
+// The constants of keys_kernel's one-multiply cell lookup (bh_tree.hpp, key_of_fast), written behind the root
+// box by whoever sets it: box[4], box[5] = 2^Dm / width per axis; box[6], box[7] = the distance from a grid
+// line, in cells, beyond which the lookup is provably the bisection's result (2.0 = never: degenerate or
+// non-finite box, or a box so far from the origin that its grid lines are not resolved to a quarter cell).
+__device__ __forceinline__ void write_key_consts(double *__restrict__ box, int Dm)
+{
+    const double side = (double)(1u << Dm);
+    const double eps = (double)(Dm + 8) * 1.1102230246251565e-16 * side;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const double lo = box[2 * a], hi = box[2 * a + 1];
+        const double w = hi - lo, big = fmax(fabs(lo), fabs(hi));
+        const double scale = side / w, margin = eps * (big / w);
+        const bool ok = isfinite(scale) && scale > 0.0 && margin < 0.25;      // (a NaN margin fails the compare)
+        box[4 + a] = ok ? scale : 0.0;
+        box[6 + a] = ok ? margin : 2.0;
+    }
+}
+
 }  // namespace bh

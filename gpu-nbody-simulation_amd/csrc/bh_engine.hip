@@ -234,7 +234,7 @@ int enqueue_build_t(bh_ctx *c)
             hipLaunchKernelGGL((bounds_partial<Real2>), dim3(nbb), dim3(kBlock), 0, st, pos, n, c->partial);
             c->partial_count = (int)nbb;
         }
-        hipLaunchKernelGGL(bounds_final, dim3(1), dim3(kBlock), 0, st, c->partial, c->partial_count, c->box, c->ctr);
+        hipLaunchKernelGGL(bounds_final, dim3(1), dim3(kBlock), 0, st, c->partial, c->partial_count, c->box, c->ctr, Dm);
         c->partial_count = 0;
     }   // else: let_box_kernel has set the global box and cleared the counters
 
@@ -629,7 +629,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
 #endif
     }
     A(&c->bsum_u32, std::max<size_t>(blocks_for(cap + 1, kTile), blocks_for(std::min<int64_t>(cap, 1 << 22) + 1, kBlock * kSmallItems)) + 8);
-    A(&c->partial, 4 * (std::max<size_t>(1024, blocks_for(cap, kWave)) + 2)); A(&c->box, 4);
+    A(&c->partial, 4 * (std::max<size_t>(1024, blocks_for(cap, kWave)) + 2)); A(&c->box, 8);
     A(&c->ctr, 1);
     if (c->exact) {
         A(&c->gd, c->node_cap); A(&c->ld, c->node_cap);
@@ -1277,7 +1277,7 @@ int bh_let_build(bh_ctx *c)
     BH_HIP(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     hipLaunchKernelGGL(let_box_kernel, dim3(1), dim3(64), 0, st, c->all_bounds, c->world * kLetBoxes, c->box, c->ctr,
-                       c->let_ctr);
+                       c->let_ctr, c->Dm);
     int rc = enqueue_build(c);
     if (rc) return rc;
     const int64_t nq = c->quads_local;

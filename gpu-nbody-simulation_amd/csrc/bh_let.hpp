@@ -30,6 +30,7 @@
 
 #include "bh_nodes.hpp"
 #include "bh_prims.hpp"
+#include "bh_bounds.hpp"
 
 namespace bh {
 
@@ -50,7 +51,8 @@ struct LetCounters {
 // all_bounds: (world * kLetBoxes) x {xmin, xmax, ymin, ymax} raw (unpadded) bounds of slices of every
 // rank's bodies.  One wave: global box with the reference's padding (project.cu:553-570).
 __global__ __launch_bounds__(kWave) void let_box_kernel(const double *__restrict__ all_bounds, int nboxes,
-                                                         double *__restrict__ box, TreeCounters *ctr, LetCounters *lc)
+                                                         double *__restrict__ box, TreeCounters *ctr, LetCounters *lc,
+                                                         int Dm)
 {
     if (blockIdx.x != 0) return;
     double xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(kWave) void let_box_kernel(const double *__restrict
     double pad = 0.1 * span;
     if (span == 0.0) pad = 1e-6;
     box[0] = xlo - pad; box[1] = xhi + pad; box[2] = ylo - pad; box[3] = yhi + pad;
+    write_key_consts(box, Dm);
     ctr->n_internal = 0; ctr->overflow = 0;
     ctr->visits = 0; ctr->interactions = 0; ctr->wave_nodes = 0; ctr->wave_quads = 0;
 }

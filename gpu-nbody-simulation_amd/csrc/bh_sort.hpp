@@ -327,22 +327,35 @@ __device__ __forceinline__ uint32_t bs_scan256(uint32_t v, uint32_t *sm, uint32_
     return base + inc - v;
 }
 
-// m <= 1,024 * ITEMS keys of one bucket: stable LSD passes over the low `passes` bytes, keys in registers
-// between passes (wave w owns the contiguous keys [w * 64 * ITEMS, ...) as in radix_scatter_w), ranks by
-// ballot matching, one LDS buffer.
+// m <= 1,024 * ITEMS keys of one bucket: stable LSD passes over the key bytes that differ inside the bucket,
+// keys in registers between passes (wave w owns the contiguous keys [w * 64 * ITEMS, ...) as in
+// radix_scatter_w), ranks by ballot matching over the bits of the byte that differ, one LDS buffer.
 template <int ITEMS>
-__device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in, int m, int passes,
-                                                uint64_t *skey, uint32_t (*woff)[kBuckets], uint32_t *sm,
+__device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in, int m, uint64_t *skey,
+                                                uint32_t (*woff)[kBuckets], uint32_t *sm, uint64_t *s_or,
                                                 uint64_t *__restrict__ kout, uint32_t *__restrict__ vout)
 {
     const int t = threadIdx.x, w = wave_id(), l = lane_id();
     const int wbase = w * (kWave * ITEMS);
     uint64_t key[ITEMS];
+    const uint64_t k0 = in[0];
+    uint64_t x = 0;
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const int i = wbase + r * kWave + l;
         key[r] = (i < m) ? in[i] : ~0ull;
+        x |= (i < m) ? (key[r] ^ k0) & kKeyMask40 : 0ull;
     }
+    for (int k = t; k < kBsWaves * kBuckets; k += kBsThreads) (&woff[0][0])[k] = 0;
+    // which key bits differ inside the bucket: only those bytes need a pass, only those bits a ballot
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x |= __shfl_xor(x, o);
+    if (l == 0) s_or[w] = x;
+    __syncthreads();
+    x = 0;
+#pragma unroll
+    for (int k = 0; k < kBsWaves; ++k) x |= s_or[k];
+    const int passes = x ? (64 - __clzll(x) + 7) / 8 : 0;
     if (passes == 0) {                                          // all keys equal (or one key): order is final
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
@@ -351,11 +364,9 @@ __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in,
         }
         return;
     }
-    const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
-        for (int k = t; k < kBsWaves * kBuckets; k += kBsThreads) (&woff[0][0])[k] = 0;
-        __syncthreads();                                        // (also: last pass's reads of skey are done)
+        const uint32_t live = (uint32_t)(x >> shift) & 255u;    // bits of this byte that differ (uniform)
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const int i = wbase + r * kWave + l;
@@ -382,13 +393,12 @@ __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in,
             const bool valid = i < m;
             const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
             uint64_t peers = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (d >> b) & 1u;
+            for (uint32_t rest = live; rest; rest &= rest - 1) {                    // uniform loop over the live bits
+                const bool bit = (d & (rest & (0u - rest))) != 0u;
                 const uint64_t bal = __ballot(bit);
-                peers &= bit ? bal : ~bal;
+                peers &= bal ^ ((uint64_t)bit - 1ull);                              // bit ? bal : ~bal
             }
-            const uint32_t rank = __popcll(peers & lt);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
             uint32_t o = 0;
             if (valid) o = woff[w][d];
             if (valid) skey[o + rank] = key[r];
@@ -401,6 +411,8 @@ __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in,
                 const int i = wbase + r * kWave + l;
                 key[r] = (i < m) ? skey[i] : ~0ull;
             }
+            for (int k = t; k < kBsWaves * kBuckets; k += kBsThreads) (&woff[0][0])[k] = 0;
+            __syncthreads();
         }
     }
     for (int i = t; i < m; i += kBsThreads) {
@@ -439,6 +451,13 @@ __global__ __launch_bounds__(kBsThreads) void bucket_sort_kernel(uint64_t *__res
     uint64_t *ko = kout + start;
     uint32_t *vo = vout + start;
 
+    if (m <= 1 * kBsThreads) { bucket_sort_lds<1>(in, m, skey, woff, sm, s_or, ko, vo); return; }
+    if (m <= 2 * kBsThreads) { bucket_sort_lds<2>(in, m, skey, woff, sm, s_or, ko, vo); return; }
+    if (m <= 4 * kBsThreads) { bucket_sort_lds<4>(in, m, skey, woff, sm, s_or, ko, vo); return; }
+    if (m <= 6 * kBsThreads) { bucket_sort_lds<6>(in, m, skey, woff, sm, s_or, ko, vo); return; }
+    if (m <= 8 * kBsThreads) { bucket_sort_lds<8>(in, m, skey, woff, sm, s_or, ko, vo); return; }
+    if (m <= kBucketCap) { bucket_sort_lds<kBucketItemsMax>(in, m, skey, woff, sm, s_or, ko, vo); return; }
+
     // which key bits differ inside the bucket: only those bytes need a pass
     const uint64_t k0 = in[0];
     uint64_t x = 0;
@@ -451,13 +470,6 @@ __global__ __launch_bounds__(kBsThreads) void bucket_sort_kernel(uint64_t *__res
 #pragma unroll
     for (int k = 0; k < kBsWaves; ++k) x |= s_or[k];
     const int passes = x ? (64 - __clzll(x) + 7) / 8 : 0;
-
-    if (m <= 1 * kBsThreads) { bucket_sort_lds<1>(in, m, passes, skey, woff, sm, ko, vo); return; }
-    if (m <= 2 * kBsThreads) { bucket_sort_lds<2>(in, m, passes, skey, woff, sm, ko, vo); return; }
-    if (m <= 4 * kBsThreads) { bucket_sort_lds<4>(in, m, passes, skey, woff, sm, ko, vo); return; }
-    if (m <= 6 * kBsThreads) { bucket_sort_lds<6>(in, m, passes, skey, woff, sm, ko, vo); return; }
-    if (m <= 8 * kBsThreads) { bucket_sort_lds<8>(in, m, passes, skey, woff, sm, ko, vo); return; }
-    if (m <= kBucketCap) { bucket_sort_lds<kBucketItemsMax>(in, m, passes, skey, woff, sm, ko, vo); return; }
 
     // ---- the bucket does not fit: the same stable passes through global memory, 1,024 keys per round, by this
     // workgroup alone (all its waves share one L1: workgroup barriers order the stores and the loads)

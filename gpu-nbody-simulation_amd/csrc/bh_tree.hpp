@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void bounds_partial(const Real2 *__restrict
 
 // final reduction + the padding of project.cu:553-570; also clears the per-step counters
 __global__ __launch_bounds__(kBlock) void bounds_final(const double *__restrict__ partial, int nb,
-                                                        double *__restrict__ box, TreeCounters *ctr)
+                                                        double *__restrict__ box, TreeCounters *ctr, int Dm)
 {
     __shared__ double sm[4][kWavesPerBlock];
     double xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(kBlock) void bounds_final(const double *__restrict_
         double pad = 0.1 * span;
         if (span == 0.0) pad = 1e-6;
         box[0] = xlo - pad; box[1] = xhi + pad; box[2] = ylo - pad; box[3] = yhi + pad;
+        write_key_consts(box, Dm);
         ctr->n_internal = 0; ctr->overflow = 0;
         ctr->visits = 0; ctr->interactions = 0; ctr->wave_nodes = 0; ctr->wave_quads = 0;
     }
@@ -170,6 +171,38 @@ __device__ __forceinline__ uint64_t key_of(double x, double y, double x0, double
     return k;
 }
 
+// The same key without the bisection, for almost every body.  The reference's cell boundaries are midpoints of
+// midpoints, each rounded once: boundary k of the finest grid is within Dm * ulp(M)/2 of x0 + k * w / 2^Dm
+// (M = max |box corner|, w = the box width; the halving is exact and averaging does not amplify the operands'
+// errors).  t = (x - x0) * (2^Dm / w), computed in fp64, is within 2^(Dm-50) cells of the exact quotient.  So
+// when t is farther than `margin` = (Dm + 8) * 2^-53 * 2^Dm * M / w from an integer, every comparison of the
+// bisection is decided the same way and floor(t) IS the cell; the rest (a body within ~2^-28 cell widths of a
+// grid line, a body on the box edge, non-finite input: ~1 body in 10^8) takes key_of.  The curve digits
+// then come from the integer cell coordinates.  Same keys, bit for bit (tests: every tree comparison against
+// the oracle, and test_fast_keys_equal_the_bisection_keys on grid-line and box-edge positions).
+template <bool HILBERT>
+__device__ __forceinline__ uint64_t key_of_fast(double x, double y, double x0, double x1, double y0, double y1, int Dm,
+                                                double scale_x, double scale_y, double margin_x, double margin_y)
+{
+    const double side = (double)(1u << Dm);
+    const double tx = (x - x0) * scale_x, ty = (y - y0) * scale_y;
+    const double fx = floor(tx), fy = floor(ty);
+    const double rx = tx - fx, ry = ty - fy;
+    // (written so that a NaN or an infinity anywhere makes the test fail)
+    const bool sure = rx > margin_x && rx < 1.0 - margin_x && ry > margin_y && ry < 1.0 - margin_y &&
+                      fx >= 0.0 && fx < side && fy >= 0.0 && fy < side;
+    if (!sure) return key_of<HILBERT>(x, y, x0, x1, y0, y1, Dm);
+    const uint32_t ix = (uint32_t)fx, iy = (uint32_t)fy;
+    uint64_t k = 0;
+    int state = 0;
+    for (int l = Dm - 1; l >= 0; --l) {
+        const int c = (int)(((ix >> l) & 1u) | (((iy >> l) & 1u) << 1));
+        k = (k << 2) | (uint64_t)(HILBERT ? hilbert_digit(state, c) : c);
+        state = hilbert_next(state, c);
+    }
+    return k;
+}
+
 // PACK: the body index is written into bits 40..63 of the key word instead of the index array (bh_sort.hpp).
 // samples != nullptr (bucket sort, bh_sort.hpp): workgroup 0 also produces the 256 splitters of this build --
 // the keys, in THIS build's box, of the positions that stood at the ranks j * n / 256 of the previous build's
@@ -215,7 +248,9 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
     }
     const int64_t i = ((int64_t)blockIdx.x - (samples != nullptr ? 1 : 0)) * kBlock + threadIdx.x;
     if (i >= n) return;
-    const uint64_t k = key_of<HILBERT>((double)pos[i].x, (double)pos[i].y, x0, x1, y0, y1, Dm);
+    const uint64_t k = HILBERT ? key_of_fast<HILBERT>((double)pos[i].x, (double)pos[i].y, x0, x1, y0, y1, Dm, box[4], box[5],
+                                                      box[6], box[7])
+                               : key_of<HILBERT>((double)pos[i].x, (double)pos[i].y, x0, x1, y0, y1, Dm);
     if (PACK) {
         keys[i] = k | ((uint64_t)i << kPackShift);
     } else {

@@ -56,6 +56,54 @@ def test_mixed_accelerations_and_tree(kind, n):
     np.testing.assert_allclose(root["mass"], m.sum(), rtol=1e-6)
 
 
+def test_fast_keys_equal_the_bisection_keys():
+    """keys_kernel takes a body's cell from one multiply per axis when the body is provably clear of every
+    grid line and falls back to the reference's bisection otherwise.  Bodies placed EXACTLY on the
+    bisection's own (rounded) midpoints, one ulp below and one ulp above them, on both axes, at every depth,
+    and on the box corners: the exported tree is the oracle's, cell by cell and occupant by occupant."""
+    rng = np.random.default_rng(17)
+    corners = np.array([[-1.0, -1.0], [1.0, 1.0], [-1.0, 1.0], [1.0, -1.0]])
+    lo, hi = corners.min(0), corners.max(0)
+    span = max(hi - lo)
+    pad = 0.1 * span
+    box = (lo[0] - pad, hi[0] + pad, lo[1] - pad, hi[1] + pad)               # bounds_final's formula
+
+    def midpoint(a, b, depth):
+        for _ in range(depth):                                                # a random path of the bisection
+            mid = (a + b) / 2
+            if rng.random() < 0.5:
+                a = mid
+            else:
+                b = mid
+        return (a + b) / 2
+
+    pts = [corners, rng.uniform(-0.999, 0.999, (6000, 2))]
+    for _ in range(1500):
+        d = int(rng.integers(0, 20))
+        bx, by = midpoint(box[0], box[1], d), midpoint(box[2], box[3], d)
+        if not (-0.999 < bx < 0.999 and -0.999 < by < 0.999):
+            continue
+        xs = [bx, np.nextafter(bx, -np.inf), np.nextafter(bx, np.inf)]
+        ys = [by, np.nextafter(by, -np.inf), np.nextafter(by, np.inf)]
+        free = rng.uniform(-0.999, 0.999, 6)
+        pts.append(np.array([[xs[0], free[0]], [xs[1], free[1]], [xs[2], free[2]],
+                             [free[3], ys[0]], [free[4], ys[1]], [free[5], ys[2]],
+                             [xs[0], ys[0]], [xs[1], ys[2]], [xs[2], ys[1]]]))
+    p = np.concatenate(pts)
+    n = len(p)
+    m = rng.uniform(0.5, 1.0, n) * 1e-12
+    v = np.zeros((n, 2))
+    with engine(n) as e:
+        e.upload(p, v, m)
+        e.build_tree()
+        nodes, depth = e.export_tree()
+    rn, rd = O.canonical_tree(O.build_tree(p, m, 21))
+    assert len(nodes) == len(rn) and np.array_equal(depth, rd)
+    for f in ("xmin", "xmax", "ymin", "ymax", "particle"):
+        assert np.array_equal(nodes[f], rn[f]), f
+    assert np.array_equal(nodes["child"] == -1, rn["child"] == -1)
+
+
 def test_mixed_keeps_displacements_below_fp32_resolution():
     n, steps = 20000, 5
     m, p, v = IC.make("uniform", n, 8, quasi_static=True)   # |v| <= 1e-9 per step against |x| ~ 0.1
