@@ -358,15 +358,18 @@ int enqueue_build_t(bh_ctx *c)
             hipLaunchKernelGGL((prep_kernel<EXACT, SI, Real2, Real, SReal2, SReal>), dim3(nbs), dim3(kBlock), 0, st,
                                c->keys_sorted, c->perm, pos, mass, c->cnt, c->bsum_u32, (SReal2 *)c->spos,
                                (SReal *)c->smass, c->terms, c->bsum_d3, c->coarse, n, Dm);
+            constexpr bool TSRC = !EXACT && std::is_same<Real2, SReal2>::value;   // fp32 state: terms from the sorted copies
             if (nbs <= 8u * kBlock) {
                 // few tiles: every workgroup sums the tile totals before it itself (no scan_top2 launch)
-                hipLaunchKernelGGL((scan_apply2<EXACT, SI, true>), dim3(nbs), dim3(kBlock), 0, st, c->cnt, c->bsum_u32,
-                                   c->terms, c->bsum_d3, (int)nbs, n, c->cell_first, c->internal_cap, c->ctr);
+                hipLaunchKernelGGL((scan_apply2<EXACT, SI, true, TSRC>), dim3(nbs), dim3(kBlock), 0, st, c->cnt, c->bsum_u32,
+                                   c->terms, c->bsum_d3, (int)nbs, n, c->cell_first, c->internal_cap, c->ctr,
+                                   (const float2 *)c->spos, (const float *)c->smass);
             } else {
                 hipLaunchKernelGGL(scan_top2, dim3(EXACT ? 1 : 2), dim3(kBlock), 0, st, c->bsum_u32, c->bsum_d3,
                                    (int)nbs, c->ctr);
-                hipLaunchKernelGGL((scan_apply2<EXACT, SI, false>), dim3(nbs), dim3(kBlock), 0, st, c->cnt, c->bsum_u32,
-                                   c->terms, c->bsum_d3, (int)nbs, n, c->cell_first, c->internal_cap, c->ctr);
+                hipLaunchKernelGGL((scan_apply2<EXACT, SI, false, TSRC>), dim3(nbs), dim3(kBlock), 0, st, c->cnt, c->bsum_u32,
+                                   c->terms, c->bsum_d3, (int)nbs, n, c->cell_first, c->internal_cap, c->ctr,
+                                   (const float2 *)c->spos, (const float *)c->smass);
             }
         };
         if (ITEMS == kItems && n <= (int64_t)1 << 21) scan_part(std::integral_constant<int, 4>{});

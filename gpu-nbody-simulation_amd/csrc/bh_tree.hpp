@@ -302,11 +302,13 @@ __global__ __launch_bounds__(kBlock) void prep_kernel(const uint64_t *__restrict
                 spos[i] = SReal2{static_cast<SReal>(p.x), static_cast<SReal>(p.y)};
                 smass[i] = static_cast<SReal>(m);
                 const d3 t{(double)m, (double)m * (double)p.x, (double)m * (double)p.y};
-                terms[i] = t;
+                // fp32 state: the sorted copies ARE the state's values, scan_apply2 forms the same terms from
+                // them (12 bytes read instead of 24 written here and 24 read there)
+                if (!std::is_same<Real2, SReal2>::value) terms[i] = t;
                 tsum += t;
             }
         } else if (!EXACT && i == n) {
-            terms[n] = d3{0.0, 0.0, 0.0};
+            if (!std::is_same<Real2, SReal2>::value) terms[n] = d3{0.0, 0.0, 0.0};
         }
     }
     uint32_t utot;
@@ -355,13 +357,16 @@ __global__ __launch_bounds__(kBlock) void scan_top2(uint32_t *__restrict__ bsum_
 // FOLD: bsum_* hold the raw tile TOTALS written by prep_kernel (at most 8 * kBlock of them) and every
 // workgroup sums the tiles before it itself -- one launch less for launches of few bodies, where
 // scan_top2 is nothing but its ~5 us of launch; workgroup 0 publishes the cell count.
-template <bool EXACT, int ITEMS, bool FOLD>
+// TSRC: the prefix-sum terms (m, m x, m y) are formed from the sorted fp32 copies instead of read from `terms`
+template <bool EXACT, int ITEMS, bool FOLD, bool TSRC = false>
 __global__ __launch_bounds__(kBlock) void scan_apply2(uint32_t *__restrict__ cnt,
                                                        const uint32_t *__restrict__ bsum_u32,
                                                        d3 *__restrict__ terms,
                                                        const d3 *__restrict__ bsum_d3, int nbs, int64_t n,
                                                        uint32_t *__restrict__ cell_first,
-                                                       int64_t internal_cap, TreeCounters *ctr)
+                                                       int64_t internal_cap, TreeCounters *ctr,
+                                                       const float2 *__restrict__ spos = nullptr,
+                                                       const float *__restrict__ smass = nullptr)
 {
     __shared__ uint32_t smu[kWavesPerBlock + 1];
     __shared__ d3 smd[kWavesPerBlock + 1];
@@ -405,7 +410,16 @@ __global__ __launch_bounds__(kBlock) void scan_apply2(uint32_t *__restrict__ cnt
         }
         ucarry += utot;
         if (!EXACT) {
-            const d3 t = (i <= n) ? terms[i] : d3{0.0, 0.0, 0.0};
+            d3 t{0.0, 0.0, 0.0};
+            if (TSRC) {
+                if (i < n) {
+                    const float2 p = spos[i];
+                    const float m = smass[i];
+                    t = d3{(double)m, (double)m * (double)p.x, (double)m * (double)p.y};
+                }
+            } else if (i <= n) {
+                t = terms[i];
+            }
             d3 dtot;
             const d3 dex = block_exclusive_sum(t, smd, dtot);
             if (i <= n) terms[i] = dcarry + dex;
