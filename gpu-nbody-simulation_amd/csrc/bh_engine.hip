@@ -113,6 +113,7 @@ struct bh_ctx {
     int64_t *gid = nullptr;             // 64-bit id per body, caller order
     uint32_t *group_cost = nullptr;     // cost of every 64-body group in the last walk (sorted order)
     const void **walk_consts = nullptr; // device block {aux, spos, smass, 0} for the assembly walk's bucket path
+    bool aux_full = false;              // aux[] holds every node's record (after an export), not only the buckets'
     bool group_cost_valid = false;
     int64_t group_cost_n = 0;           // number of groups group_cost describes
     bool sort_pack = true;              // BH_SORT_PACK=0: separate key and index arrays in every pass (A/B)
@@ -211,6 +212,26 @@ __global__ __launch_bounds__(kBlock) void reorder_state_kernel(uint32_t *__restr
     pos2[s] = pos[b]; vel2[s] = vel[b]; mass2[s] = mass[b]; acc2[s] = acc[b];
     orig2[s] = orig ? orig[b] : b;                            // orig == nullptr: slots still are caller indices
     perm[s] = (uint32_t)s;
+}
+
+// fp32 node kernel.  full_aux: also the {first body, count} record of every node (the host export needs them;
+// a step only needs those of bucket leaves).  Inputs are what the build left on the device, so it can be run
+// again after the build (export_tree_host).
+static void launch_nodes_fast(bh_ctx *c, bool full_aux, hipStream_t st)
+{
+    const int64_t n = c->n;
+    const int Dm = c->Dm;
+    // one thread per subdivided cell; I <= (n-1)*Dm and <= internal_cap
+    const int64_t span = std::max<int64_t>(1, std::min<int64_t>(c->internal_cap, std::max<int64_t>(n - 1, 0) * (int64_t)std::max(1, Dm)));
+    const unsigned nbc = blocks_for(span, kBlock);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(nbc), dim3(kBlock), 0, st, c->keys_sorted, c->coarse, c->cnt, c->cell_first,
+                           c->spos, c->smass, c->box, c->terms, n, Dm, c->cfg.theta, c->internal_cap, c->qf, c->aux,
+                           c->ctr);
+    };
+    if (c->compat) { if (full_aux) go(nodes_fast_kernel<true, true>); else go(nodes_fast_kernel<true, false>); }
+    else { if (full_aux) go(nodes_fast_kernel<false, true>); else go(nodes_fast_kernel<false, false>); }
+    c->aux_full = full_aux;
 }
 
 template <bool EXACT, bool STATE64 = EXACT, int ITEMS = kItems>
@@ -390,17 +411,7 @@ int enqueue_build_t(bh_ctx *c)
                            c->cnt, c->cell_first, pos, mass, c->box, n, Dm, c->internal_cap, c->gd, c->ld, c->self_node,
                            c->cell_depth, c->com_pending, c->ctr);
     } else {
-        // one thread per subdivided cell; I <= (n-1)*Dm and <= internal_cap
-        const int64_t span = std::max<int64_t>(1, std::min<int64_t>(c->internal_cap, std::max<int64_t>(n - 1, 0) * (int64_t)std::max(1, Dm)));
-        const unsigned nbc = blocks_for(span, kBlock);
-        if (c->compat)
-            hipLaunchKernelGGL((nodes_fast_kernel<true>), dim3(nbc), dim3(kBlock), 0, st, c->keys_sorted, c->coarse, c->cnt,
-                               c->cell_first, c->spos, c->smass, c->box, c->terms, n, Dm, c->cfg.theta,
-                               c->internal_cap, c->qf, c->aux, c->ctr);
-        else
-            hipLaunchKernelGGL((nodes_fast_kernel<false>), dim3(nbc), dim3(kBlock), 0, st, c->keys_sorted, c->coarse, c->cnt,
-                               c->cell_first, c->spos, c->smass, c->box, c->terms, n, Dm, c->cfg.theta,
-                               c->internal_cap, c->qf, c->aux, c->ctr);
+        launch_nodes_fast(c, false, st);
     }
     // 7. exact bottom-up mass pass (ComputeMass, project.cu:473-502): ONE launch for small trees (the climb of
     //    com_up_kernel), one launch per depth for large ones, where the climb's coherence traffic costs more
@@ -956,6 +967,11 @@ static int export_tree_host(bh_ctx *c, std::vector<bh_tree_node> &out, std::vect
         BH_HIP(c, hipMemcpy(ld.data(), c->ld, nn * sizeof(LinkD), hipMemcpyDeviceToHost));
     } else {
         const int64_t nq = (int64_t)h.n_internal + 1;      // quad 0 = root
+        if (!c->aux_full && c->n > 0) {                    // the step's node kernel writes bucket records only
+            launch_nodes_fast(c, true, c->stream);
+            BH_HIP(c, hipGetLastError());
+            BH_HIP(c, hipStreamSynchronize(c->stream));
+        }
         qf.resize(nq); aux.resize(4 * nq);
         BH_HIP(c, hipMemcpy(qf.data(), c->qf, nq * sizeof(QuadF), hipMemcpyDeviceToHost));
         BH_HIP(c, hipMemcpy(aux.data(), c->aux, 4 * nq * sizeof(NodeAux), hipMemcpyDeviceToHost));

@@ -593,7 +593,11 @@ constexpr int kMaxBucket = 1024;
 constexpr int kKeyHalo = 768;
 constexpr int kKeyWin = kBlock + 1 + kKeyHalo;
 
-template <bool COMPAT>
+// FULL_AUX: the {first body, count} record of EVERY node is written (bh_export_tree asks for it and re-runs
+// this kernel); the step itself only needs those of bucket leaves -- 32 of the 112 bytes a cell writes, and
+// 8 of the 28 KB of LDS staging.  (Asking for 7 resident workgroups instead of 5 made it SLOWER, 55 -> 58 us at N = 1M:
+// the 72-register budget costs more than the extra residency returns.)
+template <bool COMPAT, bool FULL_AUX = false>
 __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     const uint64_t *__restrict__ keys, const uint64_t *__restrict__ coarse,
     const uint32_t *__restrict__ off, const uint32_t *__restrict__ cell_first,
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     // from its position in that body's chain.  32-bit indices throughout (bh_create caps n < 2^31).
     // LDS is used twice: first as the key window of the searches, then -- after a barrier -- as the
     // staging area of the quads (28 KB instead of 36 KB per workgroup: 5 resident workgroups per CU)
-    constexpr int kStageBytes = kBlock * 28 * 4, kWinBytes = kKeyWin * 8;
+    constexpr int kStageBytes = kBlock * (FULL_AUX ? 28 : 20) * 4, kWinBytes = kKeyWin * 8;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kStageBytes > kWinBytes ? kStageBytes : kWinBytes];
     uint64_t *wkeys = reinterpret_cast<uint64_t *>(lds_raw);
     __shared__ int32_t s_wlo;
@@ -858,8 +862,12 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             put_lds(c, res_cx[c], res_cy[c], res_m[c], res_thr[c], res_child[c]);
-            stage_a[threadIdx.x * 8 + 2 * c] = res_bc[c];
-            stage_a[threadIdx.x * 8 + 2 * c + 1] = res_nc[c];
+            if (FULL_AUX) {
+                stage_a[threadIdx.x * 8 + 2 * c] = res_bc[c];
+                stage_a[threadIdx.x * 8 + 2 * c + 1] = res_nc[c];
+            } else if (res_child[c] <= -2) {                     // a bucket leaf: the walk reads its body range
+                aux[4 * ((int64_t)r + 1) + c] = NodeAux{res_bc[c], res_nc[c]};
+            }
         }
     }
     // coalesced write-out of this workgroup's quads [r_block + 1, r_block + 1 + cells)
@@ -870,9 +878,11 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
         v4 *dq = reinterpret_cast<v4 *>(qi + ((int64_t)r_block + 1) * 20);
         const v4 *sq = reinterpret_cast<const v4 *>(stage_q);
         for (uint32_t k = threadIdx.x; k < cells * 5; k += kBlock) dq[k] = sq[k];
-        v4 *da = reinterpret_cast<v4 *>(aux + 4 * ((int64_t)r_block + 1));
-        const v4 *sa = reinterpret_cast<const v4 *>(stage_a);
-        for (uint32_t k = threadIdx.x; k < cells * 2; k += kBlock) da[k] = sa[k];
+        if (FULL_AUX) {
+            v4 *da = reinterpret_cast<v4 *>(aux + 4 * ((int64_t)r_block + 1));
+            const v4 *sa = reinterpret_cast<const v4 *>(stage_a);
+            for (uint32_t k = threadIdx.x; k < cells * 2; k += kBlock) da[k] = sa[k];
+        }
     }
 }
 
