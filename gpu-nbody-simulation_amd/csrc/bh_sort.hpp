@@ -336,7 +336,10 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
 // the largest of 256 buckets was 1.5x the average on the dynamic Plummer workload at N = 1.1M.  The LDS
 // buffer therefore holds twice the average bucket of the largest launch, four times that of N = 1M.)
 constexpr int kBsThreads = 1024, kBsWaves = kBsThreads / kWave;   // 16 waves: 4 per SIMD hide the LDS round trips
-constexpr int kBucketItemsMax = 16;
+#ifndef BH_BS_ITEMS_MAX
+#define BH_BS_ITEMS_MAX 16
+#endif
+constexpr int kBucketItemsMax = BH_BS_ITEMS_MAX;
 constexpr int kBucketCap = kBucketItemsMax * kBsThreads;      // 16,384 keys (128 of the CU's 160 KB of LDS)
 constexpr int64_t kBucketMaxN = (int64_t)kBuckets * (kBucketCap / 2);       // 2,097,152 bodies
 
@@ -486,8 +489,8 @@ __global__ __launch_bounds__(kBsThreads) void bucket_sort_kernel(uint64_t *__res
     if (m <= 1 * kBsThreads) { bucket_sort_lds<1>(in, m, skey, woff, sm, s_or, ko, vo); return; }
     if (m <= 2 * kBsThreads) { bucket_sort_lds<2>(in, m, skey, woff, sm, s_or, ko, vo); return; }
     if (m <= 4 * kBsThreads) { bucket_sort_lds<4>(in, m, skey, woff, sm, s_or, ko, vo); return; }
-    if (m <= 6 * kBsThreads) { bucket_sort_lds<6>(in, m, skey, woff, sm, s_or, ko, vo); return; }
-    if (m <= 8 * kBsThreads) { bucket_sort_lds<8>(in, m, skey, woff, sm, s_or, ko, vo); return; }
+    if (kBucketItemsMax > 6 && m <= 6 * kBsThreads) { bucket_sort_lds<6>(in, m, skey, woff, sm, s_or, ko, vo); return; }
+    if (kBucketItemsMax > 8 && m <= 8 * kBsThreads) { bucket_sort_lds<8>(in, m, skey, woff, sm, s_or, ko, vo); return; }
     if (m <= kBucketCap) { bucket_sort_lds<kBucketItemsMax>(in, m, skey, woff, sm, s_or, ko, vo); return; }
 
     // which key bits differ inside the bucket: only those bytes need a pass

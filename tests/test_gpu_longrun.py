@@ -75,6 +75,9 @@ def test_config2_thousand_dynamic_steps():
             pk, vk = e.download()
             assert np.isfinite(pk).all() and np.isfinite(vk).all()
         assert e.stats().steps_done == STEPS
+        # 999 of the builds used the bucket sort (splitters from the previous build); with every body changing
+        # cell every step and the root box growing every step, no bucket ever outgrew its LDS buffer
+        assert e.stats().sort_spill_buckets == 0
         assert np.array_equal(e.masses(), m)                              # caller order survived ~60 re-orderings
         pf, vf = pk, vk
         spread = max(np.ptp(pf[:, 0]), np.ptp(pf[:, 1])) / box
