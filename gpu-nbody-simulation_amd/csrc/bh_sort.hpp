@@ -84,13 +84,9 @@ __device__ __forceinline__ uint32_t bucket_of(uint64_t key, const uint64_t *spl)
 // bucket digit of a tile, the upper bytes of the keys of a bucket -- that is every instruction of the count
 // phase.  A full wave whose lanes all hold the same digit therefore adds 64 through one lane, and its ranks
 // are the lane numbers (no ballot matching).
-// Measured per site at N = 1M, sort ms frozen / drifting bodies (same box): nowhere 0.058 / 0.075; in the bucket
-// pass's histogram and scatter 0.053 / 0.074; also in the upper byte passes of bucket_sort_kernel 0.051 / 0.083
-// -- there a wave's 64 keys are mostly, but on moving bodies not entirely, of one digit, and the test is paid
-// on top of the matching.  So: the bucket pass only.
-#ifndef BH_UT_BS
-#define BH_UT_BS 0
-#endif
+// (Used in the bucket pass only -- histogram and scatter, where a tile's keys fall into one or two buckets; in
+// the byte passes of bucket_sort_kernel the test cost more on moving bodies than it saved on frozen ones:
+// sort 0.051 / 0.083 ms frozen / drifting with it, 0.053 / 0.074 without, N = 1M.)
 __device__ __forceinline__ bool wave_same_digit(uint32_t d, bool valid)
 {
     return __ballot(valid) == ~0ull && __ballot(d != (uint32_t)__builtin_amdgcn_readfirstlane((int)d)) == 0ull;
@@ -236,17 +232,20 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
     __shared__ uint32_t sval[PACK ? 1 : TILE];
     __shared__ uint32_t sm[kWavesPerBlock + 1];
     __shared__ uint8_t sdig[BUCKET ? TILE : 1];             // BUCKET: the bucket of every key of the sorted tile
+    // per wave: digit -> mask of the lanes that hold it in the current round (see bucket_sort_lds below: an LDS
+    // OR + read + clear per key instead of ~8 vector instructions per digit bit of ballot matching)
+    __shared__ uint64_t match[kWavesPerBlock][R];
     const int t = threadIdx.x, w = wave_id(), l = lane_id();
     for (int d = t; d < R; d += kBlock)
 #pragma unroll
-        for (int k = 0; k < kWavesPerBlock; ++k) woff[k][d] = 0;
+        for (int k = 0; k < kWavesPerBlock; ++k) { woff[k][d] = 0; match[k][d] = 0ull; }
     __syncthreads();
 
     const int64_t tile_base = (int64_t)blockIdx.x * TILE;
     const int64_t base = tile_base + (int64_t)w * (kWave * ITEMS);
     uint64_t key[ITEMS];
     uint32_t val[PACK ? 1 : ITEMS];
-    uint32_t dig[ITEMS];
+    uint32_t dig[ITEMS], rank[ITEMS], npeer[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = base + r * kWave + l;
@@ -254,7 +253,27 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
         key[r] = valid ? kin[i] : ~0ull;
         if (!PACK) val[r] = valid ? vin[i] : 0u;
         dig[r] = BUCKET ? (valid ? (uint32_t)dig8[i] : 0u) : (uint32_t)(key[r] >> shift) & (R - 1);
-        wave_count_digit<BUCKET>(woff[w], dig[r], valid);
+    }
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const bool valid = base + r * kWave + l < n;
+        const uint32_t d = dig[r];
+        if (BUCKET && wave_same_digit(d, valid)) {              // (uniform) a full wave inside one bucket: the usual case
+            rank[r] = (uint32_t)l;
+            npeer[r] = (uint32_t)kWave;
+            if (l == 0) woff[w][d] += (uint32_t)kWave;
+            continue;
+        }
+        uint64_t peers = 0;
+        if (valid) (void)__hip_atomic_fetch_or(&match[w][d], 1ull << l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_wave_barrier();
+        if (valid) peers = match[w][d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid) match[w][d] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        rank[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        npeer[r] = (uint32_t)__popcll(peers);
+        if (valid && rank[r] == 0) woff[w][d] += npeer[r];      // one lane per digit; this wave's row only
     }
     __syncthreads();
     {
@@ -285,30 +304,20 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
     }
     __syncthreads();
 
-    const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
-        const int64_t i = base + r * kWave + l;
-        const bool valid = i < n;
+        const bool valid = base + r * kWave + l < n;
         const uint32_t d = dig[r];
-        uint64_t peers = __ballot(valid);
-        if (!(BUCKET && wave_same_digit(d, valid))) {
-#pragma unroll
-            for (int b = 0; b < BITS; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const uint64_t bal = __ballot(bit);
-                peers &= bit ? bal : ~bal;
-            }
-        }
-        const uint32_t rank = __popcll(peers & lt);
         uint32_t o = 0;
         if (valid) o = woff[w][d];                          // every peer reads the same word ...
+        __builtin_amdgcn_wave_barrier();
         if (valid) {
-            skey[o + rank] = key[r];
-            if (!PACK) sval[o + rank] = val[r];
-            if (BUCKET) sdig[o + rank] = (uint8_t)d;
+            skey[o + rank[r]] = key[r];
+            if (!PACK) sval[o + rank[r]] = val[r];
+            if (BUCKET) sdig[o + rank[r]] = (uint8_t)d;
         }
-        if (valid && rank == 0) woff[w][d] = o + (uint32_t)__popcll(peers);   // ... before its leader advances it
+        if (valid && rank[r] == 0) woff[w][d] = o + npeer[r];   // ... before the first peer advances it
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     const int64_t left = n - tile_base;
@@ -334,14 +343,11 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
 // (A root box that moves by a depth-12 cell width per step re-aligns every finer cell, so in a dense core --
 // where a bucket is a few such cells -- the re-keyed splitters are only as good as random ones at that scale:
 // the largest of 256 buckets was 1.5x the average on the dynamic Plummer workload at N = 1.1M.  The LDS
-// buffer therefore holds twice the average bucket of the largest launch, four times that of N = 1M.)
+// buffer therefore holds twice the average bucket of the largest launch, three times that of N = 1M.)
 constexpr int kBsThreads = 1024, kBsWaves = kBsThreads / kWave;   // 16 waves: 4 per SIMD hide the LDS round trips
-#ifndef BH_BS_ITEMS_MAX
-#define BH_BS_ITEMS_MAX 16
-#endif
-constexpr int kBucketItemsMax = BH_BS_ITEMS_MAX;
-constexpr int kBucketCap = kBucketItemsMax * kBsThreads;      // 16,384 keys (128 of the CU's 160 KB of LDS)
-constexpr int64_t kBucketMaxN = (int64_t)kBuckets * (kBucketCap / 2);       // 2,097,152 bodies
+constexpr int kBucketItemsMax = 12;
+constexpr int kBucketCap = kBucketItemsMax * kBsThreads;      // 12,288 keys (96 KB; + 16 KB offsets + 32 KB match tables)
+constexpr int64_t kBucketMaxN = (int64_t)kBuckets * (kBucketCap / 2);       // 1,572,864 bodies
 
 // exclusive scan of the 256 values held by threads 0..255 of the 1,024-thread workgroup (every thread calls;
 // threads 256.. pass 0 and ignore the result)
@@ -362,9 +368,14 @@ __device__ __forceinline__ uint32_t bs_scan256(uint32_t v, uint32_t *sm, uint32_
 // m <= 1,024 * ITEMS keys of one bucket: stable LSD passes over the key bytes that differ inside the bucket,
 // keys in registers between passes (wave w owns the contiguous keys [w * 64 * ITEMS, ...) as in
 // radix_scatter_w), ranks by ballot matching over the bits of the byte that differ, one LDS buffer.
+// Who shares my digit?  Matching by ballots costs ~8 vector instructions per digit bit and the kernel was bound
+// by exactly those (8.4 M vector instructions per launch at N = 1M, 2,050 per wave).  Instead every wave
+// owns a 256-entry table of 64-bit lane masks in LDS: a lane ORs its lane bit into the entry of its digit, reads
+// the entry back -- the mask of its peers -- and clears it (LDS instructions of one wave execute in order).
 template <int ITEMS>
 __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in, int m, uint64_t *skey,
-                                                uint32_t (*woff)[kBuckets], uint32_t *sm, uint64_t *s_or,
+                                                uint32_t (*woff)[kBuckets], uint64_t (*match)[kBuckets],
+                                                uint32_t *sm, uint64_t *s_or,
                                                 uint64_t *__restrict__ kout, uint32_t *__restrict__ vout)
 {
     const int t = threadIdx.x, w = wave_id(), l = lane_id();
@@ -378,8 +389,8 @@ __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in,
         key[r] = (i < m) ? in[i] : ~0ull;
         x |= (i < m) ? (key[r] ^ k0) & kKeyMask40 : 0ull;
     }
-    for (int k = t; k < kBsWaves * kBuckets; k += kBsThreads) (&woff[0][0])[k] = 0;
-    // which key bits differ inside the bucket: only those bytes need a pass, only those bits a ballot
+    for (int k = t; k < kBsWaves * kBuckets; k += kBsThreads) { (&woff[0][0])[k] = 0; (&match[0][0])[k] = 0ull; }
+    // which key bits differ inside the bucket: only those bytes need a pass
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) x |= __shfl_xor(x, o);
     if (l == 0) s_or[w] = x;
@@ -398,12 +409,23 @@ __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in,
     }
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
-        const uint32_t live = (uint32_t)(x >> shift) & 255u;    // bits of this byte that differ (uniform)
+        // peers, ranks and counts first (kept in registers), wave totals per digit by the first peer
+        uint32_t rank[ITEMS], cnt[ITEMS];
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const int i = wbase + r * kWave + l;
-            if (BH_UT_BS && p >= 2) wave_count_digit<true>(woff[w], (uint32_t)(key[r] >> shift) & 255u, i < m);
-            else wave_count_digit<false>(woff[w], (uint32_t)(key[r] >> shift) & 255u, i < m);
+            const bool valid = i < m;
+            const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+            uint64_t peers = 0;
+            if (valid) (void)__hip_atomic_fetch_or(&match[w][d], 1ull << l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_wave_barrier();
+            if (valid) peers = match[w][d];
+            __builtin_amdgcn_wave_barrier();
+            if (valid) match[w][d] = 0ull;
+            __builtin_amdgcn_wave_barrier();
+            rank[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            cnt[r] = (uint32_t)__popcll(peers);
+            if (valid && rank[r] == 0) woff[w][d] += cnt[r];    // one lane per digit; this wave's row only
         }
         __syncthreads();
         {
@@ -425,19 +447,12 @@ __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in,
             const int i = wbase + r * kWave + l;
             const bool valid = i < m;
             const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
-            uint64_t peers = __ballot(valid);
-            if (!(BH_UT_BS && p >= 2 && wave_same_digit(d, valid))) {
-                for (uint32_t rest = live; rest; rest &= rest - 1) {                // uniform loop over the live bits
-                    const bool bit = (d & (rest & (0u - rest))) != 0u;
-                    const uint64_t bal = __ballot(bit);
-                    peers &= bal ^ ((uint64_t)bit - 1ull);                          // bit ? bal : ~bal
-                }
-            }
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
             uint32_t o = 0;
-            if (valid) o = woff[w][d];
-            if (valid) skey[o + rank] = key[r];
-            if (valid && rank == 0) woff[w][d] = o + (uint32_t)__popcll(peers);
+            if (valid) o = woff[w][d];                          // every peer reads the same word ...
+            __builtin_amdgcn_wave_barrier();
+            if (valid) skey[o + rank[r]] = key[r];
+            if (valid && rank[r] == 0) woff[w][d] = o + cnt[r]; // ... before the first peer advances it
+            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
         if (p + 1 < passes) {
@@ -468,6 +483,7 @@ __global__ __launch_bounds__(kBsThreads) void bucket_sort_kernel(uint64_t *__res
 {
     __shared__ uint64_t skey[kBucketCap];
     __shared__ uint32_t woff[kBsWaves][kBuckets];
+    __shared__ uint64_t match[kBsWaves][kBuckets];
     __shared__ uint32_t sm[8];
     __shared__ uint64_t s_or[kBsWaves];
     __shared__ uint32_t s_start, s_m;
@@ -486,12 +502,12 @@ __global__ __launch_bounds__(kBsThreads) void bucket_sort_kernel(uint64_t *__res
     uint64_t *ko = kout + start;
     uint32_t *vo = vout + start;
 
-    if (m <= 1 * kBsThreads) { bucket_sort_lds<1>(in, m, skey, woff, sm, s_or, ko, vo); return; }
-    if (m <= 2 * kBsThreads) { bucket_sort_lds<2>(in, m, skey, woff, sm, s_or, ko, vo); return; }
-    if (m <= 4 * kBsThreads) { bucket_sort_lds<4>(in, m, skey, woff, sm, s_or, ko, vo); return; }
-    if (kBucketItemsMax > 6 && m <= 6 * kBsThreads) { bucket_sort_lds<6>(in, m, skey, woff, sm, s_or, ko, vo); return; }
-    if (kBucketItemsMax > 8 && m <= 8 * kBsThreads) { bucket_sort_lds<8>(in, m, skey, woff, sm, s_or, ko, vo); return; }
-    if (m <= kBucketCap) { bucket_sort_lds<kBucketItemsMax>(in, m, skey, woff, sm, s_or, ko, vo); return; }
+    if (m <= 1 * kBsThreads) { bucket_sort_lds<1>(in, m, skey, woff, match, sm, s_or, ko, vo); return; }
+    if (m <= 2 * kBsThreads) { bucket_sort_lds<2>(in, m, skey, woff, match, sm, s_or, ko, vo); return; }
+    if (m <= 4 * kBsThreads) { bucket_sort_lds<4>(in, m, skey, woff, match, sm, s_or, ko, vo); return; }
+    if (m <= 6 * kBsThreads) { bucket_sort_lds<6>(in, m, skey, woff, match, sm, s_or, ko, vo); return; }
+    if (m <= 8 * kBsThreads) { bucket_sort_lds<8>(in, m, skey, woff, match, sm, s_or, ko, vo); return; }
+    if (m <= kBucketCap) { bucket_sort_lds<kBucketItemsMax>(in, m, skey, woff, match, sm, s_or, ko, vo); return; }
 
     // which key bits differ inside the bucket: only those bytes need a pass
     const uint64_t k0 = in[0];
