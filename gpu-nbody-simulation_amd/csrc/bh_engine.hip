@@ -51,6 +51,7 @@ struct bh_ctx {
     bool walk_asm = true;          // BH_WALK_ASM=0: the C++ loop everywhere (A/B)
     int sort_bucket = 1;           // 1: bucket sort when the previous build's sorted positions are this body set's
                                    // (BH_SORT_BUCKET=0: always the LSD passes; 2: always the bucket sort, tests)
+    bool last_sort_bucket = false, last_sort_packed = false;   // what the last build's sort was (bh_stats bytes)
     int64_t samples_n = -1;        // spos holds the sorted positions of a build of this many bodies (-1: none)
     uint64_t *splitters = nullptr;
     uint8_t *sort_dig = nullptr;   // bucket of every key (written by the histogram, read by the scatter)
@@ -271,6 +272,7 @@ int enqueue_build_t(bh_ctx *c)
         bool bucket = false;
         if constexpr (!EXACT)
             bucket = pack && n >= 2 && n <= kBucketMaxN && (c->sort_bucket == 2 || (c->sort_bucket == 1 && c->samples_n == n));
+        c->last_sort_bucket = bucket; c->last_sort_packed = pack;
         if (pack)
             hipLaunchKernelGGL((keys_kernel<Real2, true, true>), dim3(blocks_for(n, kBlock) + (bucket ? 1 : 0)), dim3(kBlock),
                                0, st, pos, c->box, c->keys[0], c->vals[0], n, Dm,
@@ -1110,11 +1112,17 @@ int bh_stats(bh_ctx *c, bh_stats_t *out)
         BH_HIP(c, hipEventElapsedTime(&ms, c->ev_grp[0], c->ev_grp[1])); out->sort_ms = ms;
         BH_HIP(c, hipEventElapsedTime(&ms, c->ev_grp[1], c->ev_grp[2])); out->scan_ms = ms;
         BH_HIP(c, hipEventElapsedTime(&ms, c->ev_grp[2], c->ev_build[1])); out->nodes_ms = ms;
-        // algorithmic bytes per body of one build: keys 20 (fp64 state: 28), per radix
-        // pass 8 (histogram) + 24 (scatter), prep 76, scans 59, nodes 140 (exact mode: 96-byte geometry+links)
+        // algorithmic bytes per body of one build.  keys: position in, key (+ index) out;
+        // sort: per LSD pass 8 (histogram) + 16 (scatter of packed keys; 24 with a separate index array), or the
+        // bucket sort's 9 + 17 + 20 (histogram + bucket byte, scatter, in-LDS sort with the unpacked write-out);
+        // prep: key, index, position and mass in, count and sorted copies out (+ 24 of prefix-sum terms when the
+        // state is fp64); scans: counts in and out, cell starts, terms -> prefix sums; nodes: ~0.72 cells per body,
+        // each reading its key window share, ranks and five prefix sums and writing an 80-byte quad
         const int passes = (2 * c->Dm + kSortBits - 1) / kSortBits;
-        const uint64_t per_body = (c->state64 ? 28u : 20u) + 32u * (uint64_t)passes + 76u + 59u + 140u;
-        out->build_bytes = (uint64_t)c->n * per_body;
+        const uint64_t keys_b = (c->state64 ? 24u : 16u) + (c->last_sort_packed ? 0u : 4u);
+        const uint64_t sort_b = c->last_sort_bucket ? 46u : (uint64_t)passes * (c->last_sort_packed ? 24u : 32u);
+        const uint64_t prep_b = c->state64 ? 76u : 40u, scan_b = c->state64 ? 59u : 47u, nodes_b = c->exact ? 140u : 117u;
+        out->build_bytes = (uint64_t)c->n * (keys_b + sort_b + prep_b + scan_b + nodes_b);
         out->walk_bytes = out->wave_nodes ? (uint64_t)c->n * 44u + out->wave_nodes * 20u : 0u;
     }
     return BH_OK;
