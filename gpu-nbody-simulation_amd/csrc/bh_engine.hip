@@ -54,7 +54,7 @@ struct bh_ctx {
     bool last_sort_bucket = false, last_sort_packed = false;   // what the last build's sort was (bh_stats bytes)
     int64_t samples_n = -1;        // spos holds the sorted positions of a build of this many bodies (-1: none)
     uint64_t *splitters = nullptr;
-    uint8_t *sort_dig = nullptr;   // bucket of every key (written by the histogram, read by the scatter)
+    uint16_t *sort_dig = nullptr;  // bucket of every key (written by the histogram, read by the scatter)
     bool sort_wave_rank = true;    // radix_scatter_w (wave-private ranking); experiments: BH_SORT_WAVE_RANK=0
     int build_items = 0;           // 0 = automatic, else keys per thread in the sort / scan kernels (2, 4, 8)
     bool hilbert = false;                // fp32 mode: Hilbert-ordered keys (BH_HILBERT=0 disables, A/B)  // BH_WALK_PIPE / BH_WALK_XCD override (A/B)
@@ -271,12 +271,17 @@ int enqueue_build_t(bh_ctx *c)
         // bucket sort (bh_sort.hpp): one counting pass by splitters from the previous build + one in-LDS sort per bucket
         bool bucket = false;
         if constexpr (!EXACT)
-            bucket = pack && n >= 2 && n <= kBucketMaxN && (c->sort_bucket == 2 || (c->sort_bucket == 1 && c->samples_n == n));
+            bucket = pack && n >= 2 && n <= kBucketMaxNBig && (c->sort_bucket == 2 || (c->sort_bucket == 1 && c->samples_n == n));
+        const int nb = (n <= kBucketMaxN) ? kBuckets : kBucketsBig;
+        // sample positions behind the splitters: two per bucket where the key workgroups run long enough to hide the
+        // sample workgroups (256 buckets: above 262k bodies; 1,024 buckets: above 3M), one per bucket otherwise
+        const int ns = (nb == kBuckets) ? ((n > (int64_t)1 << 18) ? 2 * kBuckets : kBuckets)
+                                        : ((n > (int64_t)3 << 20) ? kMaxSplitSamples : kBucketsBig);
         c->last_sort_bucket = bucket; c->last_sort_packed = pack;
         if (pack)
-            hipLaunchKernelGGL((keys_kernel<Real2, true, true>), dim3(blocks_for(n, kBlock) + (bucket ? 1 : 0)), dim3(kBlock),
+            hipLaunchKernelGGL((keys_kernel<Real2, true, true>), dim3(blocks_for(n, kBlock) + (bucket ? ns / kWave : 0)), dim3(kBlock),
                                0, st, pos, c->box, c->keys[0], c->vals[0], n, Dm,
-                               bucket ? (const float2 *)c->spos : nullptr, c->splitters);
+                               bucket ? (const float2 *)c->spos : nullptr, c->splitters, nb, ns);
         else if (c->hilbert)
             hipLaunchKernelGGL((keys_kernel<Real2, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
                                c->box, c->keys[0], c->vals[0], n, Dm);
@@ -305,13 +310,17 @@ int enqueue_build_t(bh_ctx *c)
 #endif
         if (bucket) {
             constexpr int SI = (ITEMS == kItems ? kSortItems : ITEMS);
-            hipLaunchKernelGGL((radix_hist<SI, 8, true>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->radix_counts, n, 0,
-                               (int)nbl, c->splitters, c->sort_dig);
-            hipLaunchKernelGGL(radix_rowscan, dim3(kBuckets), dim3(kBlock), 0, st, c->radix_counts, c->bsum_sort, (int)nbl);
-            hipLaunchKernelGGL((radix_scatter_w<SI, 8, 1, true>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->vals[0],
-                               c->keys[1], c->vals[1], c->radix_counts, c->bsum_sort, n, 0, (int)nbl, c->sort_dig);
-            hipLaunchKernelGGL(bucket_sort_kernel, dim3(kBuckets), dim3(kBsThreads), 0, st, c->keys[1], c->keys[0], c->vals[0],
-                               c->bsum_sort, &c->ctr->sort_spills);
+            auto pass = [&](auto bits_tag) {
+                constexpr int NBITS = decltype(bits_tag)::value;
+                hipLaunchKernelGGL((radix_hist<SI, NBITS, true>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->radix_counts, n,
+                                   0, (int)nbl, c->splitters, c->sort_dig);
+                hipLaunchKernelGGL(radix_rowscan, dim3(1 << NBITS), dim3(kBlock), 0, st, c->radix_counts, c->bsum_sort, (int)nbl);
+                hipLaunchKernelGGL((radix_scatter_w<SI, NBITS, 1, true>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->vals[0],
+                                   c->keys[1], c->vals[1], c->radix_counts, c->bsum_sort, n, 0, (int)nbl, c->sort_dig);
+            };
+            if (nb == kBuckets) pass(std::integral_constant<int, 8>{}); else pass(std::integral_constant<int, 10>{});
+            hipLaunchKernelGGL(bucket_sort_kernel, dim3(nb), dim3(kBsThreads), 0, st, c->keys[1], c->keys[0], c->vals[0],
+                               c->bsum_sort, nb, &c->ctr->sort_spills);
             cur = 0;
         } else if (c->sort_wave_rank) {
             // default: kSortBits-wide digits, wave-private ranking, digit-sorted write-out
@@ -634,10 +643,12 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     A(&c->keys[0], cap); A(&c->keys[1], cap); A(&c->vals[0], cap); A(&c->vals[1], cap);
     A(&c->cnt, cap + 1);
     { const size_t nbl = std::max<size_t>(blocks_for(cap, kSortTile), blocks_for(std::min<int64_t>(cap, 1 << 22), kBlock * kSmallItems));
-      A(&c->radix_counts, (size_t)(1 << kSortBits) * nbl);
-      A(&c->bsum_sort, (1 << kSortBits) + 8);
-      A(&c->splitters, kBuckets);
-      if (!c->exact) A(&c->sort_dig, (size_t)std::min<int64_t>(cap, kBucketMaxN) + 16);
+      // (the bucket pass of launches above 1.5M bodies counts 1,024 buckets per tile)
+      const size_t big = (!c->exact && cap > kBucketMaxN) ? (size_t)kBucketsBig * blocks_for(std::min<int64_t>(cap, kBucketMaxNBig), kSortTile) : 0;
+      A(&c->radix_counts, std::max<size_t>((size_t)(1 << kSortBits) * nbl, big));
+      A(&c->bsum_sort, kBucketsBig + 8);
+      A(&c->splitters, kBucketsBig);
+      if (!c->exact) A(&c->sort_dig, (size_t)std::min<int64_t>(cap, kBucketMaxNBig) + 16);
 #ifdef BHGPU_EXPERIMENTS
       c->os_status_words = (int64_t)kMaxPasses * nbl * kRadix;
       A(&c->os_status, c->os_status_words); A(&c->os_ghist, kMaxPasses * kRadix); A(&c->os_counter, kMaxPasses);

@@ -68,15 +68,19 @@ constexpr int kSortBits = 8;
 // keys_kernel guarantees -- so (keys_sorted, perm) is bit-identical to the LSD sort's.  A bucket that does
 // not fit (bodies that moved wildly, a root box that jumped and scrambled the curve) is sorted by its
 // workgroup through global memory: correct, slow, and gone at the next build.
-constexpr int kBuckets = 256;
-static_assert(kBuckets == kBlock, "one thread per bucket / splitter");
+// 256 buckets up to 1.5M bodies, 1,024 up to 6.3M (BITS = 8 / 10 in the counting pass): the average bucket stays
+// at most half of what one workgroup sorts in LDS.
+constexpr int kBuckets = 256, kBucketsBig = 1024;
+constexpr int kDigits = 256;                              // the in-LDS sort's own 8-bit digits
+constexpr int kMaxSplitSamples = 2048;                    // sample positions sorted by keys_kernel's splitter workgroup
 constexpr uint64_t kKeyMask40 = (1ull << 40) - 1;
 // largest j with spl[j] <= key (spl sorted, spl[0] = 0)
+template <int NB>
 __device__ __forceinline__ uint32_t bucket_of(uint64_t key, const uint64_t *spl)
 {
     int b = 0;
 #pragma unroll
-    for (int s = kBuckets / 2; s >= 1; s >>= 1) b += (spl[b + s] <= key) ? s : 0;
+    for (int s = NB / 2; s >= 1; s >>= 1) b += (spl[b + s] <= key) ? s : 0;
     return (uint32_t)b;
 }
 
@@ -109,12 +113,12 @@ __global__ __launch_bounds__(kBlock) void radix_hist(const uint64_t *__restrict_
                                                       uint32_t *__restrict__ counts, int64_t n,
                                                       int shift, int nblocks,
                                                       const uint64_t *__restrict__ splitters = nullptr,
-                                                      uint8_t *__restrict__ dig8 = nullptr)
+                                                      uint16_t *__restrict__ dig16 = nullptr)
 {
     constexpr int R = 1 << BITS;
     __shared__ uint32_t h[R];
-    __shared__ uint64_t spl[BUCKET ? kBuckets : 1];
-    if (BUCKET) spl[threadIdx.x] = splitters[threadIdx.x];
+    __shared__ uint64_t spl[BUCKET ? R : 1];
+    if (BUCKET) for (int d = threadIdx.x; d < R; d += kBlock) spl[d] = splitters[d];
     for (int d = threadIdx.x; d < R; d += kBlock) h[d] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * (kBlock * ITEMS);
@@ -123,8 +127,8 @@ __global__ __launch_bounds__(kBlock) void radix_hist(const uint64_t *__restrict_
         const int64_t i = base + r * kBlock + threadIdx.x;
         const bool valid = i < n;
         const uint64_t k = valid ? keys[i] : 0ull;
-        const uint32_t d = BUCKET ? bucket_of(k & kKeyMask40, spl) : (uint32_t)(k >> shift) & (R - 1);
-        if (BUCKET && valid) dig8[i] = (uint8_t)d;              // the scatter reads it back instead of searching again
+        const uint32_t d = BUCKET ? bucket_of<R>(k & kKeyMask40, spl) : (uint32_t)(k >> shift) & (R - 1);
+        if (BUCKET && valid) dig16[i] = (uint16_t)d;            // the scatter reads it back instead of searching again
         wave_count_digit<BUCKET>(h, d, valid);
     }
     __syncthreads();
@@ -217,9 +221,9 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
                                                            const uint32_t *__restrict__ offs,
                                                            const uint32_t *__restrict__ row_total, int64_t n,
                                                            int shift, int nblocks,
-                                                           const uint8_t *__restrict__ dig8 = nullptr)
+                                                           const uint16_t *__restrict__ dig16 = nullptr)
 {
-    static_assert(!BUCKET || (PACK == 1 && BITS == 8), "the bucket pass moves packed keys");
+    static_assert(!BUCKET || PACK == 1, "the bucket pass moves packed keys");
     // (4) the tile is first sorted by digit INTO LDS, then written out in that order: the keys a digit
     // has in a tile leave as one contiguous run instead of separate partial-line writes from
     // different rounds
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
     __shared__ uint64_t skey[TILE];
     __shared__ uint32_t sval[PACK ? 1 : TILE];
     __shared__ uint32_t sm[kWavesPerBlock + 1];
-    __shared__ uint8_t sdig[BUCKET ? TILE : 1];             // BUCKET: the bucket of every key of the sorted tile
+    __shared__ uint16_t sdig[BUCKET ? TILE : 1];            // BUCKET: the bucket of every key of the sorted tile
     // per wave: digit -> mask of the lanes that hold it in the current round (see bucket_sort_lds below: an LDS
     // OR + read + clear per key instead of ~8 vector instructions per digit bit of ballot matching)
     __shared__ uint64_t match[kWavesPerBlock][R];
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
         const bool valid = i < n;
         key[r] = valid ? kin[i] : ~0ull;
         if (!PACK) val[r] = valid ? vin[i] : 0u;
-        dig[r] = BUCKET ? (valid ? (uint32_t)dig8[i] : 0u) : (uint32_t)(key[r] >> shift) & (R - 1);
+        dig[r] = BUCKET ? (valid ? (uint32_t)dig16[i] : 0u) : (uint32_t)(key[r] >> shift) & (R - 1);
     }
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
         if (valid) {
             skey[o + rank[r]] = key[r];
             if (!PACK) sval[o + rank[r]] = val[r];
-            if (BUCKET) sdig[o + rank[r]] = (uint8_t)d;
+            if (BUCKET) sdig[o + rank[r]] = (uint16_t)d;
         }
         if (valid && rank[r] == 0) woff[w][d] = o + npeer[r];   // ... before the first peer advances it
         __builtin_amdgcn_wave_barrier();
@@ -347,7 +351,8 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
 constexpr int kBsThreads = 1024, kBsWaves = kBsThreads / kWave;   // 16 waves: 4 per SIMD hide the LDS round trips
 constexpr int kBucketItemsMax = 12;
 constexpr int kBucketCap = kBucketItemsMax * kBsThreads;      // 12,288 keys (96 KB; + 16 KB offsets + 32 KB match tables)
-constexpr int64_t kBucketMaxN = (int64_t)kBuckets * (kBucketCap / 2);       // 1,572,864 bodies
+constexpr int64_t kBucketMaxN = (int64_t)kBuckets * (kBucketCap / 2);       // 1,572,864 bodies with 256 buckets
+constexpr int64_t kBucketMaxNBig = (int64_t)kBucketsBig * (kBucketCap / 2);  // 6,291,456 with 1,024
 
 // exclusive scan of the 256 values held by threads 0..255 of the 1,024-thread workgroup (every thread calls;
 // threads 256.. pass 0 and ignore the result)
@@ -374,7 +379,7 @@ __device__ __forceinline__ uint32_t bs_scan256(uint32_t v, uint32_t *sm, uint32_
 // the entry back -- the mask of its peers -- and clears it (LDS instructions of one wave execute in order).
 template <int ITEMS>
 __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in, int m, uint64_t *skey,
-                                                uint32_t (*woff)[kBuckets], uint64_t (*match)[kBuckets],
+                                                uint32_t (*woff)[kDigits], uint64_t (*match)[kDigits],
                                                 uint32_t *sm, uint64_t *s_or,
                                                 uint64_t *__restrict__ kout, uint32_t *__restrict__ vout)
 {
@@ -389,7 +394,7 @@ __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in,
         key[r] = (i < m) ? in[i] : ~0ull;
         x |= (i < m) ? (key[r] ^ k0) & kKeyMask40 : 0ull;
     }
-    for (int k = t; k < kBsWaves * kBuckets; k += kBsThreads) { (&woff[0][0])[k] = 0; (&match[0][0])[k] = 0ull; }
+    for (int k = t; k < kBsWaves * kDigits; k += kBsThreads) { (&woff[0][0])[k] = 0; (&match[0][0])[k] = 0ull; }
     // which key bits differ inside the bucket: only those bytes need a pass
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) x |= __shfl_xor(x, o);
@@ -430,13 +435,13 @@ __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in,
         __syncthreads();
         {
             uint32_t c = 0;
-            if (t < kBuckets) {
+            if (t < kDigits) {
 #pragma unroll
                 for (int k = 0; k < kBsWaves; ++k) c += woff[k][t];
             }
             uint32_t all;
             uint32_t run = bs_scan256(c, sm, all);
-            if (t < kBuckets) {
+            if (t < kDigits) {
 #pragma unroll
                 for (int k = 0; k < kBsWaves; ++k) { const uint32_t cc = woff[k][t]; woff[k][t] = run; run += cc; }
             }
@@ -461,7 +466,7 @@ __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in,
                 const int i = wbase + r * kWave + l;
                 key[r] = (i < m) ? skey[i] : ~0ull;
             }
-            for (int k = t; k < kBsWaves * kBuckets; k += kBsThreads) (&woff[0][0])[k] = 0;
+            for (int k = t; k < kBsWaves * kDigits; k += kBsThreads) (&woff[0][0])[k] = 0;
             __syncthreads();
         }
     }
@@ -478,21 +483,27 @@ __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in,
 __global__ __launch_bounds__(kBsThreads) void bucket_sort_kernel(uint64_t *__restrict__ bucketed,
                                                                   uint64_t *__restrict__ kout,
                                                                   uint32_t *__restrict__ vout,
-                                                                  const uint32_t *__restrict__ bucket_total,
+                                                                  const uint32_t *__restrict__ bucket_total, int nb,
                                                                   uint32_t *__restrict__ spills)
 {
     __shared__ uint64_t skey[kBucketCap];
-    __shared__ uint32_t woff[kBsWaves][kBuckets];
-    __shared__ uint64_t match[kBsWaves][kBuckets];
+    __shared__ uint32_t woff[kBsWaves][kDigits];
+    __shared__ uint64_t match[kBsWaves][kDigits];
     __shared__ uint32_t sm[8];
     __shared__ uint64_t s_or[kBsWaves];
     __shared__ uint32_t s_start, s_m;
     const int t = threadIdx.x, w = wave_id(), l = lane_id();
     {
-        const uint32_t mine = (t < kBuckets) ? bucket_total[t] : 0u;
-        uint32_t all;
-        const uint32_t ex = bs_scan256(mine, sm, all);
-        if (t == (int)blockIdx.x) { s_start = ex; s_m = mine; }
+        // where this bucket starts: exclusive scan of the nb <= 1,024 bucket totals, one per thread
+        const uint32_t mine = (t < nb) ? bucket_total[t] : 0u;
+        const uint32_t inc = wave_inclusive_sum(mine);
+        __shared__ uint32_t s_wtot[kBsWaves];
+        if (l == kWave - 1) s_wtot[w] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+#pragma unroll
+        for (int k = 0; k < kBsWaves; ++k) base += (k < w) ? s_wtot[k] : 0u;
+        if (t == (int)blockIdx.x) { s_start = base + inc - mine; s_m = mine; }
         __syncthreads();
     }
     const int64_t start = s_start;
@@ -530,16 +541,16 @@ __global__ __launch_bounds__(kBsThreads) void bucket_sort_kernel(uint64_t *__res
     const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
-        if (t < kBuckets) hist[t] = 0;
-        for (int k = t; k < kBsWaves * kBuckets; k += kBsThreads) (&woff[0][0])[k] = 0;
+        if (t < kDigits) hist[t] = 0;
+        for (int k = t; k < kBsWaves * kDigits; k += kBsThreads) (&woff[0][0])[k] = 0;
         __syncthreads();
         for (int i = t; i < m; i += kBsThreads) atomicAdd(&hist[(uint32_t)(src[i] >> shift) & 255u], 1u);
         __syncthreads();
         {
-            const uint32_t c = (t < kBuckets) ? hist[t] : 0u;
+            const uint32_t c = (t < kDigits) ? hist[t] : 0u;
             uint32_t all;
             const uint32_t e = bs_scan256(c, sm, all);
-            if (t < kBuckets) hist[t] = e;
+            if (t < kDigits) hist[t] = e;
         }
         __syncthreads();
         for (int i0 = 0; i0 < m; i0 += kBsThreads) {
@@ -563,7 +574,7 @@ __global__ __launch_bounds__(kBsThreads) void bucket_sort_kernel(uint64_t *__res
                 dst[o] = key;
             }
             __syncthreads();
-            if (t < kBuckets) {
+            if (t < kDigits) {
                 uint32_t sacc = 0;
 #pragma unroll
                 for (int k = 0; k < kBsWaves; ++k) { sacc += woff[k][t]; woff[k][t] = 0; }

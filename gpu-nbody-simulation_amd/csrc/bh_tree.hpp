@@ -204,9 +204,9 @@ __device__ __forceinline__ uint64_t key_of_fast(double x, double y, double x0, d
 }
 
 // PACK: the body index is written into bits 40..63 of the key word instead of the index array (bh_sort.hpp).
-// samples != nullptr (bucket sort, bh_sort.hpp): workgroup 0 also produces the 256 splitters of this build --
-// the keys, in THIS build's box, of the positions that stood at the ranks j * n / 256 of the previous build's
-// sorted order, sorted (rank by counting; splitter 0 is 0).  Bodies move little between two builds, so
+// samples != nullptr (bucket sort, bh_sort.hpp): ns / 64 extra workgroups produce the nb (256 or 1,024) splitters
+// of this build -- the keys, in THIS build's box, of the positions that stood at the ranks j * n / nb of the previous
+// build's sorted order (ns >= nb of them, powers of two), sorted; splitter 0 is 0.  Bodies move little between two builds, so
 // the splitters cut the new keys into near-equal buckets, whatever happened to the root box in between.
 template <typename Real2, bool HILBERT, bool PACK = false>
 __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ pos,
@@ -214,39 +214,64 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
                                                        uint64_t *__restrict__ keys,
                                                        uint32_t *__restrict__ idx, int64_t n, int Dm,
                                                        const float2 *__restrict__ samples = nullptr,
-                                                       uint64_t *__restrict__ splitters = nullptr)
+                                                       uint64_t *__restrict__ splitters = nullptr, int nb = 0,
+                                                       int ns = 0)
 {
     const double x0 = box[0], x1 = box[1], y0 = box[2], y1 = box[3];
-    if (samples != nullptr && blockIdx.x == 0) {                // one extra workgroup (the grid is one larger)
-        __shared__ uint64_t sk[kBlock];
+    const int nsb = (samples != nullptr) ? ns / kWave : 0;      // extra workgroups in front of the key workgroups
+    if ((int)blockIdx.x < nsb) {
+        // ns sample positions -> keys -> ranks by counting -> every (ns / nb)-th in rank order is a splitter.
+        // Every one of the ns / 64 sample workgroups forms all ns keys (cheap: one multiply per axis with the
+        // box's precomputed scale -- not the exact bisection, a splitter does not have to be the key of
+        // anything, the splitters only have to be sorted) and ranks 64 of them, four threads per sample, so a
+        // sample workgroup does not outlast a key workgroup.  (Oversampling evens the buckets out when the
+        // re-keyed samples are only as good as random ones; the largest bucket decides bucket_sort_kernel's time.)
+        __shared__ uint64_t sk[kMaxSplitSamples];
         const int t = threadIdx.x;
-        uint64_t mine = 0;
-        if (t > 0) {
-            // the sample's cell by one multiply per axis -- not the exact bisection: a splitter does not have
-            // to be the key of anything, the 256 of them only have to be sorted -- then the curve digits
-            const float2 q = samples[(int64_t)t * n / kBlock];
-            const double side = (double)(1u << Dm), top = side - 1.0;
-            const double fx = fmin(fmax(((double)q.x - x0) / (x1 - x0) * side, 0.0), top);
-            const double fy = fmin(fmax(((double)q.y - y0) / (y1 - y0) * side, 0.0), top);
-            const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
-            int state = 0;
-            for (int l = Dm - 1; l >= 0; --l) {
-                const int cc = (int)(((ix >> l) & 1u) | (((iy >> l) & 1u) << 1));
-                mine = (mine << 2) | (uint64_t)(HILBERT ? hilbert_digit(state, cc) : cc);
-                state = hilbert_next(state, cc);
-            }
+        // (a sample workgroup shares its CU with key workgroups, so its time is its instruction count: 12 curve
+        // levels are plenty for a splitter, and ns, nb are powers of two -- shifts, not divisions)
+        const int Ds = (Dm < 12) ? Dm : 12, lg_ns = 31 - __clz(ns), lg_os = lg_ns - (31 - __clz(nb));
+        const double side = (double)(1u << Ds), top = side - 1.0, down = 1.0 / (double)(1u << (Dm - Ds));
+        const double sx = (box[4] > 0.0) ? box[4] * down : side / (x1 - x0), sy = (box[5] > 0.0) ? box[5] * down : side / (y1 - y0);
+        float2 qs[kMaxSplitSamples / kBlock];                    // all of this thread's sample loads in flight at once
+#pragma unroll
+        for (int k = 0; k < kMaxSplitSamples / kBlock; ++k) {
+            const int j = t + k * kBlock;
+            qs[k] = (j < ns) ? samples[((int64_t)j * n) >> lg_ns] : float2{0.f, 0.f};
         }
-        // rank by counting; the thread index in the low byte makes the 256 values distinct (one compare each)
-        const uint64_t tagged = (mine << 8) | (uint64_t)t;
-        sk[t] = tagged;
+#pragma unroll
+        for (int k = 0; k < kMaxSplitSamples / kBlock; ++k) {
+            const int j = t + k * kBlock;
+            if (j >= ns) break;
+            uint64_t mine = 0;
+            if (j > 0) {
+                const float2 q = qs[k];
+                const double fx = fmin(fmax(((double)q.x - x0) * sx, 0.0), top);
+                const double fy = fmin(fmax(((double)q.y - y0) * sy, 0.0), top);
+                const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+                int state = 0;
+                uint32_t k32 = 0;                                // 24 bits
+                for (int l = Ds - 1; l >= 0; --l) {
+                    const int cc = (int)(((ix >> l) & 1u) | (((iy >> l) & 1u) << 1));
+                    k32 = (k32 << 2) | (uint32_t)(HILBERT ? hilbert_digit(state, cc) : cc);
+                    state = hilbert_next(state, cc);
+                }
+                mine = (uint64_t)k32 << (2 * (Dm - Ds));
+            }
+            sk[j] = (mine << 11) | (uint64_t)j;                 // the sample index makes the values distinct
+        }
         __syncthreads();
+        const int sidx = (int)blockIdx.x * kWave + (t >> 2), part = t & 3, span = ns >> 2;
+        const uint64_t tagged = sk[sidx];
         int rank = 0;
 #pragma unroll 16
-        for (int j = 0; j < kBlock; ++j) rank += (sk[j] < tagged) ? 1 : 0;
-        splitters[rank] = mine;
+        for (int q = part * span; q < (part + 1) * span; ++q) rank += (sk[q] < tagged) ? 1 : 0;
+        rank += __shfl_xor(rank, 1);
+        rank += __shfl_xor(rank, 2);
+        if (part == 0 && (rank & ((1 << lg_os) - 1)) == 0) splitters[rank >> lg_os] = tagged >> 11;
         return;
     }
-    const int64_t i = ((int64_t)blockIdx.x - (samples != nullptr ? 1 : 0)) * kBlock + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x - nsb) * kBlock + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = HILBERT ? key_of_fast<HILBERT>((double)pos[i].x, (double)pos[i].y, x0, x1, y0, y1, Dm, box[4], box[5],
                                                       box[6], box[7])

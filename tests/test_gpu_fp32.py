@@ -176,13 +176,14 @@ def _sort_case(kind, n):
 @pytest.mark.parametrize("kind,n,md,precision", [("plummer", 200000, 21, "f32"), ("clumped", 30000, 8, "f32"),
                                                   ("uniform", 513, 3, "f32"), ("uniform", 2, 5, "f32"),
                                                   ("plummer", 1100000, 21, "f32"), ("uniform", 70000, 21, "mixed"),
-                                                  ("clumped", 60000, 21, "f32")])
+                                                  ("clumped", 60000, 21, "f32"), ("plummer", 2500000, 21, "f32")])
 def test_bucket_sort_equals_the_lsd_sort(monkeypatch, kind, n, md, precision):
     """From the second build on the keys are sorted by ONE counting pass over 256 buckets -- splitters = the
     previous build's sorted positions at every n/256-th rank, re-keyed in the new root box -- and an in-LDS
     sort of every bucket (BH_SORT_BUCKET=0: the five LSD passes every time).  Same stable order: the tree of
     a later build and a moving trajectory are BITWISE the same, including bodies that share a depth-cap
-    cell (equal keys keep body order) and buckets of equal keys larger than the LDS capacity."""
+    cell (equal keys keep body order) and buckets of equal keys larger than the LDS capacity.  (2.5M bodies:
+    1,024 buckets, 10-bit counting pass.)"""
     m, p, v = _sort_case(kind, n)
     prec = {"f32": G.Precision.F32, "mixed": G.Precision.MIXED}[precision]
     res, spills = [], []
