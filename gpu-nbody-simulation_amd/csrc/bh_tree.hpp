@@ -697,6 +697,9 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
         wkeys[k] = (j >= 0 && j < n) ? keys[j] : 0ull;
     }
     __syncthreads();
+#if defined(BHGPU_EXPERIMENTS) && defined(BH_NODES_EXPT2)
+    if (BH_NODES_EXPT2 == 1) return;                            // timing experiment: launch + window only
+#endif
     auto K = [&](int32_t j) -> uint64_t {
         const int32_t k = j - wlo;
         return (k >= 0 && k < kKeyWin) ? wkeys[k] : keys[j];
@@ -748,27 +751,24 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
                 lo[c] = dn; hi[c] = up;
             }
         }
+        // (the fine part, mostly in the LDS window: plain bisection -- the kernel is vector-issue bound there, and
+        // three probes per round are four times the instructions of one for half the rounds)
         bool more = true;
         while (more) {
-            uint64_t k1[NT], k2[NT], k3[NT];
-            int32_t p1[NT], p2[NT], p3[NT];
+            uint64_t k2[NT];
+            int32_t p2[NT];
 #pragma unroll
             for (int c = 0; c < NT; ++c) {
-                const int32_t len = hi[c] - lo[c];
-                p1[c] = lo[c] + len / 4; p2[c] = lo[c] + len / 2; p3[c] = lo[c] + (int32_t)((3 * (int64_t)len) / 4);
-                const bool on = len > 0;
-                k1[c] = on ? K(p1[c]) : 0ull; k2[c] = on ? K(p2[c]) : 0ull; k3[c] = on ? K(p3[c]) : 0ull;
+                p2[c] = (int32_t)(((uint32_t)lo[c] + (uint32_t)hi[c]) >> 1);
+                k2[c] = (hi[c] > lo[c]) ? K(p2[c]) : 0ull;
             }
             more = false;
 #pragma unroll
             for (int c = 0; c < NT; ++c) {
-                if (hi[c] - lo[c] > 0) {
-                    if ((k1[c] >> sh) >= target[c]) hi[c] = p1[c];
-                    else if ((k2[c] >> sh) >= target[c]) { lo[c] = p1[c] + 1; hi[c] = p2[c]; }
-                    else if ((k3[c] >> sh) >= target[c]) { lo[c] = p2[c] + 1; hi[c] = p3[c]; }
-                    else lo[c] = p3[c] + 1;
+                if (hi[c] > lo[c]) {
+                    if ((k2[c] >> sh) >= target[c]) hi[c] = p2[c]; else lo[c] = p2[c] + 1;
                 }
-                more = more || (hi[c] - lo[c] > 0);
+                more = more || (hi[c] > lo[c]);
             }
         }
 #pragma unroll
@@ -800,10 +800,41 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
 #else
     constexpr bool expt_skip = false;
 #endif
+    // Most cells hold a handful of bodies: the next eight keys, read in one round, settle the end AND the three
+    // child boundaries of every cell of at most eight bodies without a loop (the searches below are divergent
+    // per-lane loops of dependent LDS reads; a wave is as slow as its largest cell, but it no longer also pays
+    // three or four rounds for each of its small ones).
+    int32_t bnd[5];
+    bool have_bnd = false;
+    const int shc = sh - 2;
     if (d == 0) e = n;
     else if (expt_skip) e = i + 1;
-    else {                                                       // galloping, then bisection
-        int32_t a = i + 1, step = 1, b;
+    else {
+        const uint64_t cell_hi = (pfx + 1) << sh;                // keys are sorted: outside the cell <=> key >= cell_hi
+        uint64_t nk[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) nk[j] = (i + 1 + j < n) ? K(i + 1 + j) : ~0ull;
+        int inside = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) inside += (nk[j] < cell_hi) ? 1 : 0;
+        if (inside < 8) {
+            e = i + 1 + inside;
+            int below1 = 0, below2 = 0, below3 = 0;              // bodies of the cell in children < 1, < 2, < 3
+            {
+                const uint32_t dg = (uint32_t)(key >> shc) & 3u;
+                below1 += dg < 1u; below2 += dg < 2u; below3 += dg < 3u;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t dg = (j < inside) ? (uint32_t)(nk[j] >> shc) & 3u : 3u;
+                below1 += dg < 1u; below2 += dg < 2u; below3 += dg < 3u;
+            }
+            bnd[1] = i + below1; bnd[2] = i + below2; bnd[3] = i + below3;
+            have_bnd = true;
+        }
+    }
+    if (d != 0 && !expt_skip && !have_bnd) {                     // nine bodies or more: galloping, then bisection
+        int32_t a = i + 8, step = 8, b;
         for (;;) {
             b = (step > n - a) ? n : a + step;                   // no 32-bit overflow
             if (b >= n) { b = n; break; }
@@ -816,7 +847,6 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
         if (step > 2 * kCoarse && b < n && (K(b) >> sh) == pfx) { a = b; b = n; }
         e = lower_bound(a + 1, b, sh, pfx + 1);
     }
-    const int shc = sh - 2;
     const int32_t quad = (int32_t)r + 1;
 
     if (d == 0) {                                                // root record in quad 0
@@ -832,9 +862,8 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     // child boundaries first, then every global load of the four children at once: the loads are
     // independent of each other, and this kernel's time is the length of its per-thread chain of
     // dependent memory accesses (3 rounds of resident workgroups x one chain at N = 1M)
-    int32_t bnd[5];
     bnd[0] = i; bnd[4] = e;
-    {
+    if (!have_bnd) {
         const uint64_t tg[3] = {(pfx << 2) | 1ull, (pfx << 2) | 2ull, (pfx << 2) | 3ull};
         if (!expt_skip) search(std::integral_constant<int, 3>{}, i, e, shc, tg, &bnd[1]);
         else bnd[1] = bnd[2] = bnd[3] = e;
@@ -844,17 +873,26 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     uint64_t kprev[4], kcur[4];
     float2 p1[4];
     float m1[4];
+    // (only what the child's kind needs: most cells sit at the bottom of the tree, their children are single
+    // bodies or empty, and a 24-byte prefix sum per boundary is the kernel's largest gather)
 #pragma unroll
-    for (int c = 0; c < 5; ++c) ps[c] = psum[bnd[c]];
+    for (int c = 0; c < 5; ++c) {
+        bool left = c > 0 && bnd[c] - bnd[c - 1] > 1, right = c < 4 && bnd[c + 1] - bnd[c] > 1;
+#if defined(BHGPU_EXPERIMENTS) && defined(BH_NODES_EXPT2)
+        if (BH_NODES_EXPT2 == 2) left = right = false;          // timing experiment: no prefix-sum gathers
+#endif
+        ps[c] = (left || right) ? psum[bnd[c]] : d3{1.0, 1.0, 1.0};
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int32_t bc = bnd[c];
-        const bool some = bnd[c + 1] > bc;
-        offc[c] = some ? off[bc] : 0u;
-        kcur[c] = some ? K(bc) : 0ull;
-        kprev[c] = (some && bc > 0) ? K(bc - 1) : 0ull;
-        p1[c] = some ? spos[bc] : float2{0.f, 0.f};
-        m1[c] = some ? smass[bc] : 0.f;
+        const int32_t ncc = bnd[c + 1] - bc;
+        const bool sub = ncc > 1 && d + 1 < Dm;                  // a subdivided child: its rank comes from off and its keys
+        offc[c] = sub ? off[bc] : 0u;
+        kcur[c] = sub ? K(bc) : 0ull;
+        kprev[c] = (sub && bc > 0) ? K(bc - 1) : 0ull;
+        p1[c] = (ncc == 1) ? spos[bc] : float2{0.f, 0.f};
+        m1[c] = (ncc == 1) ? smass[bc] : 0.f;
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -867,7 +905,13 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
         } else if (nc > 1) {
             const d3 lo_s = ps[c], hi_s = ps[c + 1];
             const double mm = hi_s.a - lo_s.a;
-            m = (float)mm; cx = (float)((hi_s.b - lo_s.b) / mm); cy = (float)((hi_s.c - lo_s.c) / mm);
+            // one reciprocal (v_rcp_f64 + two Newton steps, ~1 ulp of fp64) instead of two fp64 divisions of ~35
+            // instructions each -- eight per cell were half of this kernel's vector instructions; the values
+            // are rounded to fp32 right here
+            double inv = __builtin_amdgcn_rcp(mm);
+            inv = fma(fma(-mm, inv, 1.0), inv, inv);
+            inv = fma(fma(-mm, inv, 1.0), inv, inv);
+            m = (float)mm; cx = (float)((hi_s.b - lo_s.b) * inv); cy = (float)((hi_s.c - lo_s.c) * inv);
             if (d + 1 == Dm) {                                   // depth-cap cell
                 if (!COMPAT && nc <= kMaxBucket) { thr = INFINITY; child = -(4 * quad + c) - 2; }
             } else {                                             // subdivided cell
@@ -902,6 +946,9 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
         typedef int32_t v4 __attribute__((ext_vector_type(4)));
         v4 *dq = reinterpret_cast<v4 *>(qi + ((int64_t)r_block + 1) * 20);
         const v4 *sq = reinterpret_cast<const v4 *>(stage_q);
+#if defined(BHGPU_EXPERIMENTS) && defined(BH_NODES_EXPT2)
+        if (BH_NODES_EXPT2 != 3)                                // timing experiment: no quad stores
+#endif
         for (uint32_t k = threadIdx.x; k < cells * 5; k += kBlock) dq[k] = sq[k];
         if (FULL_AUX) {
             v4 *da = reinterpret_cast<v4 *>(aux + 4 * ((int64_t)r_block + 1));
