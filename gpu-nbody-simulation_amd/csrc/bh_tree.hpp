@@ -639,6 +639,7 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kStageBytes > kWinBytes ? kStageBytes : kWinBytes];
     uint64_t *wkeys = reinterpret_cast<uint64_t *>(lds_raw);
     __shared__ int32_t s_wlo;
+    __shared__ double s_thr0;                                   // (size/theta)^2 at depth 0: one fp64 division per workgroup
     // The 256 quads of a workgroup are contiguous in memory (quad = rank + 1): they are assembled
     // in LDS and written out with coalesced 16-byte stores.  Storing field by field from the
     // owning lanes costs 24 scattered 4-byte stores per cell -- 18 M separate L2 write requests at
@@ -689,7 +690,12 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     const uint32_t off_pre = (r < total) ? off[i_pre] : 0u;
 
     // key window starting one body before the first cell of this workgroup
-    if (threadIdx.x == 0) s_wlo = i_pre - 1;
+    if (threadIdx.x == 0) {
+        s_wlo = i_pre - 1;
+        const double ex0 = box[1] - box[0], ey0 = box[3] - box[2];
+        const double q0 = ((ex0 > ey0) ? ex0 : ey0) / theta;   // size/theta at depth 0
+        s_thr0 = q0 * q0;
+    }
     __syncthreads();
     const int32_t wlo = s_wlo;
     for (int k = threadIdx.x; k < kKeyWin; k += kBlock) {
@@ -788,9 +794,7 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     const int Lp = (i == 0) ? -1 : shared_levels(K(i - 1), key, Dm);
     const int d = Lp + 1 + (int)(r - off_pre);                  // this cell's depth
 
-    const double ex0 = box[1] - box[0], ey0 = box[3] - box[2];
-    const double q0 = ((ex0 > ey0) ? ex0 : ey0) / theta;       // size/theta at depth 0
-    const double thr0 = q0 * q0;
+    const double thr0 = s_thr0;
 
     const int sh = 2 * (Dm - d);
     const uint64_t pfx = (d == 0) ? 0ull : (key >> sh);
