@@ -79,6 +79,7 @@ __global__ __launch_bounds__(kBlock) void bounds_final(const double *__restrict_
 {
     __shared__ double sm[4][kWavesPerBlock];
     double xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
+#pragma unroll 8
     for (int i = threadIdx.x; i < nb; i += kBlock) {
         const double a = partial[4 * i], b = partial[4 * i + 1], c = partial[4 * i + 2], d = partial[4 * i + 3];
         xlo = (a < xlo) ? a : xlo;  xhi = (xhi < b) ? b : xhi;
