@@ -118,7 +118,14 @@ __global__ __launch_bounds__(kBlock) void radix_hist(const uint64_t *__restrict_
     constexpr int R = 1 << BITS;
     __shared__ uint32_t h[R];
     __shared__ uint64_t spl[BUCKET ? R : 1];
-    if (BUCKET) for (int d = threadIdx.x; d < R; d += kBlock) spl[d] = splitters[d];
+    // A key value frequent enough to be sampled twice (bodies piled into one depth-cap cell) gets a bucket of
+    // its own: the second of two equal splitters becomes value + 1, so [value, value + 1) holds equal keys only
+    // -- already in their final order after the stable scatter, whatever their number.
+    if (BUCKET)
+        for (int d = threadIdx.x; d < R; d += kBlock) {
+            const uint64_t v = splitters[d];
+            spl[d] = (d > 0 && splitters[d - 1] == v) ? v + 1 : v;
+        }
     for (int d = threadIdx.x; d < R; d += kBlock) h[d] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * (kBlock * ITEMS);
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(kBsThreads) void bucket_sort_kernel(uint64_t *__res
 
     // ---- the bucket does not fit: the same stable passes through global memory, 1,024 keys per round, by this
     // workgroup alone (all its waves share one L1: workgroup barriers order the stores and the loads)
-    if (t == 0) atomicAdd(spills, 1u);
+    if (t == 0 && passes > 0) atomicAdd(spills, 1u);           // (a bucket of equal keys is only copied)
     uint64_t *src = in, *dst = ko;
     uint32_t *hist = reinterpret_cast<uint32_t *>(skey);        // [256] counts, then running bases
     const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
@@ -587,6 +594,7 @@ __global__ __launch_bounds__(kBsThreads) void bucket_sort_kernel(uint64_t *__res
         uint64_t *tmp = src; src = dst; dst = tmp;
     }
     // unpack where the keys ended up (element-wise, so doing it in place in kout is safe)
+#pragma unroll 8
     for (int i = t; i < m; i += kBsThreads) {
         const uint64_t k = src[i];
         ko[i] = k & kKeyMask40;

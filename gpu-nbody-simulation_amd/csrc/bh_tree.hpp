@@ -229,9 +229,11 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
         // re-keyed samples are only as good as random ones; the largest bucket decides bucket_sort_kernel's time.)
         __shared__ uint64_t sk[kMaxSplitSamples];
         const int t = threadIdx.x;
-        // (a sample workgroup shares its CU with key workgroups, so its time is its instruction count: 12 curve
-        // levels are plenty for a splitter, and ns, nb are powers of two -- shifts, not divisions)
-        const int Ds = (Dm < 12) ? Dm : 12, lg_ns = 31 - __clz(ns), lg_os = lg_ns - (31 - __clz(nb));
+        // (a sample workgroup shares its CU with key workgroups, so its time is its instruction count: ns, nb are
+        // powers of two -- shifts, not divisions.  All Dm levels: when close encounters have blown the root box up,
+        // the bodies sit in a corner of it that 12 levels do not resolve, every splitter would be the same key
+        // and one bucket would get everything.)
+        const int Ds = Dm, lg_ns = 31 - __clz(ns), lg_os = lg_ns - (31 - __clz(nb));
         const double side = (double)(1u << Ds), top = side - 1.0, down = 1.0 / (double)(1u << (Dm - Ds));
         const double sx = (box[4] > 0.0) ? box[4] * down : side / (x1 - x0), sy = (box[5] > 0.0) ? box[5] * down : side / (y1 - y0);
         float2 qs[kMaxSplitSamples / kBlock];                    // all of this thread's sample loads in flight at once
@@ -251,13 +253,11 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
                 const double fy = fmin(fmax(((double)q.y - y0) * sy, 0.0), top);
                 const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
                 int state = 0;
-                uint32_t k32 = 0;                                // 24 bits
                 for (int l = Ds - 1; l >= 0; --l) {
                     const int cc = (int)(((ix >> l) & 1u) | (((iy >> l) & 1u) << 1));
-                    k32 = (k32 << 2) | (uint32_t)(HILBERT ? hilbert_digit(state, cc) : cc);
+                    mine = (mine << 2) | (uint64_t)(HILBERT ? hilbert_digit(state, cc) : cc);
                     state = hilbert_next(state, cc);
                 }
-                mine = (uint64_t)k32 << (2 * (Dm - Ds));
             }
             sk[j] = (mine << 11) | (uint64_t)j;                 // the sample index makes the values distinct
         }

@@ -73,6 +73,14 @@ def test_stats_and_timers():
         st = e.stats()
         assert st.n_bodies == 20000 and st.steps_done == 4 and st.n_nodes == 1 + 4 * st.n_internal
         assert 0 < st.walk_ms < st.last_step_ms * 1.01 and st.build_ms > 0 and st.device_bytes > 0
+        # per kernel group of the last timed step: the groups add up to the build
+        groups = st.keys_ms + st.sort_ms + st.scan_ms + st.nodes_ms
+        assert min(st.keys_ms, st.sort_ms, st.scan_ms, st.nodes_ms) > 0 and abs(groups - st.build_ms) < 0.02 * st.build_ms + 1e-3
+        # algorithmic bytes: the 4th build sorted with the bucket sort (46 B per body instead of 5 x 24)
+        # (these bodies are heavy: close encounters blow the root box up every step, the keys collapse into a few
+        # cells and a bucket of the sort may outgrow its LDS buffer -- counted, never wrong)
+        assert st.build_bytes == 20000 * (16 + 46 + 40 + 47 + 117) and st.sort_spill_buckets >= 0
+        assert st.walk_bytes == 0                                   # needs BH_FLAG_WALK_STATS
         e.upload(p, v, m)
         assert e.stats().steps_done == 0
 

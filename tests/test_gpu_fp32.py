@@ -233,6 +233,57 @@ def test_bucket_sort_with_useless_splitters_spills_and_stays_correct(monkeypatch
         assert np.array_equal(x, y)
 
 
+def test_bucket_sort_with_bodies_piled_into_one_cell(monkeypatch):
+    """Bodies that collapse into a few depth-cap cells (what close encounters without softening do to the
+    reference's runs: the root box blows up) share their keys.  A key value frequent enough to be sampled
+    twice gets a bucket of its own -- equal keys need no sorting, whatever their number -- so the build stays
+    the LSD sort's bit for bit and nothing is sorted through memory, step after step."""
+    n = 60000
+    rng = np.random.default_rng(3)
+    p = f32(np.concatenate([rng.normal(0.25, 1e-7, (40000, 2)), rng.normal(-0.5, 1e-7, (15000, 2)),
+                            rng.uniform(-1, 1, (n - 55000, 2))]))
+    m, v = f32(rng.uniform(1e-14, 2e-14, n)), f32(rng.normal(0, 1e-9, (n, 2)))
+    res, spills = [], []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BH_SORT_BUCKET", mode)
+        with engine(n, max_depth=12, reference_compat=True) as e:
+            e.upload(p, v, m)
+            e.step(6)
+            e.build_tree()
+            nodes, depth = e.export_tree()
+            e.step(6)
+            res.append((nodes, depth) + e.download())
+            spills.append(e.stats().sort_spill_buckets)
+    for x, y in zip(res[0], res[1]):
+        assert np.array_equal(x, y)
+    assert spills == [0, 0]
+
+
+def test_bucket_sort_survives_an_exploding_root_box(monkeypatch):
+    """The reference's own regime: heavy bodies, no softening, dt = 1 -- close encounters eject bodies, the root
+    box grows by orders of magnitude within two steps and the cloud shrinks into a corner of it (the tree goes
+    from 58,000 to 485 nodes).  The splitters are re-keyed in every build's box at full depth, so the buckets
+    stay balanced through the explosion: same trajectory as with the LSD passes, bit for bit, and no bucket is
+    sorted through memory."""
+    n = 20000
+    r = np.random.default_rng(0)
+    m, p, v = f32(10.0 ** r.uniform(-2, 1, n)), f32(r.uniform(-0.1, 0.1, (n, 2))), f32(r.uniform(-1e-4, 1e-4, (n, 2)))
+    res, spills, nodes = [], [], []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BH_SORT_BUCKET", mode)
+        with engine(n, max_depth=16) as e:
+            e.upload(p, v, m)
+            e.step(2)
+            nodes.append(e.stats().n_nodes)
+            e.step(6)
+            nodes.append(e.stats().n_nodes)
+            res.append(e.download())
+            spills.append(e.stats().sort_spill_buckets)
+    assert nodes[0] > 20000 and nodes[1] < 2000                      # the explosion happened
+    assert np.array_equal(res[0][0], res[1][0], equal_nan=True) and np.array_equal(res[0][1], res[1][1], equal_nan=True)
+    assert spills == [0, 0]
+
+
 def test_multistep_trajectory_encounter_free_case(gold):
     """20 steps vs the REFERENCE's own trajectory (golden; encounter-free by construction, see
     scripts/make_golden.py): positions <= 1e-6 x box width; the velocity CHANGE (what the forces did)
