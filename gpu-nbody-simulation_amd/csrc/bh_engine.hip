@@ -277,6 +277,7 @@ int enqueue_build_t(bh_ctx *c)
         // sample workgroups (256 buckets: above 262k bodies; 1,024 buckets: above 3M), one per bucket otherwise
         const int ns = (nb == kBuckets) ? ((n > (int64_t)1 << 18) ? 2 * kBuckets : kBuckets)
                                         : ((n > (int64_t)3 << 20) ? kMaxSplitSamples : kBucketsBig);
+        static_assert(kBucketMaxN == (int64_t)1 << 20 && kBucketMaxNBig == (int64_t)1 << 22, "BASELINE configs 3 and 4 fit");
         c->last_sort_bucket = bucket; c->last_sort_packed = pack;
         if (pack)
             hipLaunchKernelGGL((keys_kernel<Real2, true, true>), dim3(blocks_for(n, kBlock) + (bucket ? ns / kWave : 0)), dim3(kBlock),
@@ -643,7 +644,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     A(&c->keys[0], cap); A(&c->keys[1], cap); A(&c->vals[0], cap); A(&c->vals[1], cap);
     A(&c->cnt, cap + 1);
     { const size_t nbl = std::max<size_t>(blocks_for(cap, kSortTile), blocks_for(std::min<int64_t>(cap, 1 << 22), kBlock * kSmallItems));
-      // (the bucket pass of launches above 1.5M bodies counts 1,024 buckets per tile)
+      // (the bucket pass of launches above 1M bodies counts 1,024 buckets per tile)
       const size_t big = (!c->exact && cap > kBucketMaxN) ? (size_t)kBucketsBig * blocks_for(std::min<int64_t>(cap, kBucketMaxNBig), kSortTile) : 0;
       A(&c->radix_counts, std::max<size_t>((size_t)(1 << kSortBits) * nbl, big));
       A(&c->bsum_sort, kBucketsBig + 8);

@@ -68,8 +68,8 @@ constexpr int kSortBits = 8;
 // keys_kernel guarantees -- so (keys_sorted, perm) is bit-identical to the LSD sort's.  A bucket that does
 // not fit (bodies that moved wildly, a root box that jumped and scrambled the curve) is sorted by its
 // workgroup through global memory: correct, slow, and gone at the next build.
-// 256 buckets up to 1.5M bodies, 1,024 up to 6.3M (BITS = 8 / 10 in the counting pass): the average bucket stays
-// at most half of what one workgroup sorts in LDS.
+// 256 buckets up to 1M bodies, 1,024 up to 4M (BITS = 8 / 10 in the counting pass): the average bucket stays
+// at most a third of what one workgroup sorts in LDS.
 constexpr int kBuckets = 256, kBucketsBig = 1024;
 constexpr int kDigits = 256;                              // the in-LDS sort's own 8-bit digits
 constexpr int kMaxSplitSamples = 2048;                    // sample positions sorted by keys_kernel's splitter workgroup
@@ -354,12 +354,14 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
 // (A root box that moves by a depth-12 cell width per step re-aligns every finer cell, so in a dense core --
 // where a bucket is a few such cells -- the re-keyed splitters are only as good as random ones at that scale:
 // the largest of 256 buckets was 1.5x the average on the dynamic Plummer workload at N = 1.1M.  The LDS
-// buffer therefore holds twice the average bucket of the largest launch, three times that of N = 1M.)
+// buffer therefore holds three times the average bucket of the largest launch.)
 constexpr int kBsThreads = 1024, kBsWaves = kBsThreads / kWave;   // 16 waves: 4 per SIMD hide the LDS round trips
 constexpr int kBucketItemsMax = 12;
 constexpr int kBucketCap = kBucketItemsMax * kBsThreads;      // 12,288 keys (96 KB; + 16 KB offsets + 32 KB match tables)
-constexpr int64_t kBucketMaxN = (int64_t)kBuckets * (kBucketCap / 2);       // 1,572,864 bodies with 256 buckets
-constexpr int64_t kBucketMaxNBig = (int64_t)kBucketsBig * (kBucketCap / 2);  // 6,291,456 with 1,024
+// (the average bucket is at most a third of what fits: the largest of the buckets of a moving workload was
+// measured at 1.5x the average)
+constexpr int64_t kBucketMaxN = (int64_t)kBuckets * (kBucketCap / 3);       // 1,048,576 bodies with 256 buckets
+constexpr int64_t kBucketMaxNBig = (int64_t)kBucketsBig * (kBucketCap / 3);  // 4,194,304 with 1,024
 
 // exclusive scan of the 256 values held by threads 0..255 of the 1,024-thread workgroup (every thread calls;
 // threads 256.. pass 0 and ignore the result)
