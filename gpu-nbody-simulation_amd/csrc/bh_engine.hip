@@ -118,7 +118,6 @@ struct bh_ctx {
     bool group_cost_valid = false;
     int64_t group_cost_n = 0;           // number of groups group_cost describes
     bool sort_pack = true;              // BH_SORT_PACK=0: separate key and index arrays in every pass (A/B)
-    bool walk_lpt = true;               // BH_WALK_LPT=0: groups in curve order (A/B)
     unsigned long long *orb_hist = nullptr;
     double *mig_send = nullptr, *mig_recv = nullptr;
 #ifdef BHGPU_EXPERIMENTS

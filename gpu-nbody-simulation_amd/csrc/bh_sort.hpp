@@ -1,19 +1,22 @@
-// bh_sort.hpp -- stable LSD radix sort of (key, body) pairs for the tree build.  Included by the
-// engine translation unit only.  Measured-and-rejected variants (the barrier-per-round scatter, the
-// look-back "onesweep" sort) are compiled only with -DBHGPU_EXPERIMENTS (scripts/, never the product).
+// bh_sort.hpp -- the sort of (key, body) pairs for the tree build.  Included by the engine translation unit
+// only.  Two sorts with the same result, the stable order by key:
 //
-//   radix_hist    : counts[digit * nblocks + block] = occurrences of digit in tile `block`
-//   radix_rowscan : one workgroup per digit: exclusive prefix along its row, row total aside
-//   radix_scatter : base(digit, block) = exclusive scan of the 256 row totals (done in-kernel)
-//                   + row prefix; stable scatter of the tile using per-round ballot matching
-// Three launches per pass (it was five with a generic three-kernel scan of the count matrix; every
-// launch costs ~6 us here, so the scan launches cost more than the sorting itself).
-// A round handles 256 consecutive elements (thread t <-> element round*256 + t), so ranks follow
-// element order and equal keys keep their input order.
+//   LSD radix sort (first build after an upload, launches above 4M bodies, exact mode): 8-bit digits, three
+//   launches per pass --
+//     radix_hist      : counts[digit * nblocks + block] = occurrences of digit in tile `block`
+//     radix_rowscan   : one workgroup per digit: exclusive prefix along its row, row total aside
+//     radix_scatter_w : base(digit, block) = exclusive scan of the 256 row totals (done in-kernel) + row
+//                       prefix; stable scatter of the tile, ranks within a wave's round from a per-wave LDS
+//                       table of lane masks
+//   bucket sort (every later build of up to 4M bodies with packed keys; see "bucket sort" below): ONE such
+//   counting pass whose digit is the key's bucket among splitters from the previous build, then
+//     bucket_sort_kernel : one workgroup sorts one bucket entirely in LDS.
 //
-// (Measured alternative, rejected: letting every scatter workgroup derive its own offsets from the
-// count matrix saves three launches per pass but re-reads the 256 x nblocks matrix per workgroup;
-// at N = 1M it took 37 us per pass against 18 us + 14 us for scatter + scan.)
+// Element order inside a tile is (wave, round, lane) = tile order and ranks follow lane order, so equal keys
+// keep their input order.  Measured-and-rejected variants (the barrier-per-round scatter, the look-back
+// "onesweep" sort) are compiled only with -DBHGPU_EXPERIMENTS (scripts/, never the product).  (Also rejected
+// in round 1: letting every scatter workgroup derive its own offsets from the count matrix -- it re-reads the
+// 256 x nblocks matrix per workgroup, 37 us per pass at N = 1M against 18 + 14 us for scatter + scan then.)
 #pragma once
 
 #include "bh_prims.hpp"
@@ -210,8 +213,9 @@ __global__ __launch_bounds__(kBlock) void radix_scatter(const uint64_t *__restri
 // kernel's time IS that chain.  Here wave w owns the contiguous keys [w * 64 * ITEMS, (w+1) * 64 * ITEMS)
 // of the tile: (1) every wave counts its digits into its own LDS histogram, (2) one barrier, the
 // histograms are turned into per-wave start offsets (digit base + tile prefix + earlier waves),
-// (3) one barrier, then each wave ranks and scatters its rounds on its own -- the only shared state
-// left is the wave's own offset row, and LDS operations of one wave are ordered.  Element order is
+// (3) one barrier, then each wave scatters its rounds on its own (ranks and counts were kept in registers
+// from step 1) -- the only shared state left is the wave's own offset row, and LDS operations of one wave are
+// ordered.  Element order is
 // (wave, round, lane) = tile order, and ranks within a round follow lane order, so the sort stays
 // stable and its output is bitwise the same.
 // PACK: the body index travels in the key word itself (bits 40..63; the keys of max_depth <= 21 are 40 bits,
