@@ -5,10 +5,13 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# BHGPU_LIB: an A/B build variant (python -m gpu_nbody_simulation_amd.build --variant ...), scripts only
-LIB_PATH = os.environ.get("BHGPU_LIB") or os.path.join(HERE, "libbhgpu.so")
+# BHGPU_LIB: an A/B build variant (scripts/build_variants.sh), for the scripts/ A/B drivers only.  It must come
+# with BHGPU_LIB_OPT_IN=1: a test or bench run that merely inherited the variable would otherwise measure a
+# variant while reporting as the product -- load() refuses that.
+PRODUCT_LIB = os.path.join(HERE, "libbhgpu.so")
+LIB_PATH = os.environ.get("BHGPU_LIB") or PRODUCT_LIB
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class bh_config(C.Structure):
@@ -82,6 +85,8 @@ SIGNATURES = {
     "bh_compute_forces": (C.c_int, [_ctx]),
     "bh_get_forces": (C.c_int, [_ctx, _dp]),
     "bh_get_accel": (C.c_int, [_ctx, _dp]),
+    "bh_get_interaction_counts": (C.c_int, [_ctx, C.POINTER(C.c_uint32)]),
+    "bh_build_info": (C.c_char_p, []),
     "bh_export_tree": (C.c_int, [_ctx, _vp, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64)]),
     "bh_write_quadtree_file": (C.c_int, [_ctx, C.c_char_p]),
     "bh_stats": (C.c_int, [_ctx, C.POINTER(bh_stats_t)]),
@@ -119,6 +124,9 @@ def load() -> C.CDLL:
     """Load libbhgpu.so; raise (never fall back) when it is missing or stale."""
     global _lib
     if _lib is None:
+        if LIB_PATH != PRODUCT_LIB and os.environ.get("BHGPU_LIB_OPT_IN") != "1":
+            raise ImportError(f"BHGPU_LIB={LIB_PATH} selects a build variant, not the product library; set "
+                              "BHGPU_LIB_OPT_IN=1 to do that on purpose (scripts/ A/B drivers), or unset BHGPU_LIB")
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -m gpu_nbody_simulation_amd.build` "
@@ -132,3 +140,8 @@ def load() -> C.CDLL:
             raise ImportError(f"libbhgpu.so ABI {lib.bh_abi_version()} != binding {ABI_VERSION}; rebuild")
         _lib = lib
     return _lib
+
+
+def is_product_library() -> bool:
+    """False when an A/B variant was loaded on purpose (BHGPU_LIB + BHGPU_LIB_OPT_IN=1)."""
+    return os.path.abspath(LIB_PATH) == os.path.abspath(PRODUCT_LIB)

@@ -67,10 +67,11 @@ def _build_to(lib: str, objdir: str, extra_flags, verbose: bool) -> str:
     hipcc = _hipcc()
     os.makedirs(objdir, exist_ok=True)
     objs = []
+    info = f'-DBHGPU_BUILD_INFO="digest={source_digest()} flags={" ".join(extra_flags) or "-"}"'
     for src, extra in UNITS:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall",
-               "-Wno-unused-function", *extra, *extra_flags, *os.environ.get("BHGPU_EXTRA_FLAGS", "").split(),
+               "-Wno-unused-function", info, *extra, *extra_flags, *os.environ.get("BHGPU_EXTRA_FLAGS", "").split(),
                "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -117,6 +117,7 @@ struct bh_ctx {
     bool aux_full = false;              // aux[] holds every node's record (after an export), not only the buckets'
     bool group_cost_valid = false;
     int64_t group_cost_n = 0;           // number of groups group_cost describes
+    uint32_t *body_counts = nullptr;    // BH_FLAG_WALK_STATS: accepted force evaluations per body (device slot order)
     bool sort_pack = true;              // BH_SORT_PACK=0: separate key and index arrays in every pass (A/B)
     unsigned long long *orb_hist = nullptr;
     double *mig_send = nullptr, *mig_recv = nullptr;
@@ -503,10 +504,16 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
 #endif
         a.group_cost = (lo == 0 && hi == c->n) ? c->group_cost : nullptr;
         a.bucket_consts = c->walk_consts;
+        a.body_counts = nullptr;
+        if (stats) {
+            if (!c->body_counts) { int rc = dev_alloc(c, &c->body_counts, (size_t)std::max<int64_t>(c->cfg.capacity, 1)); if (rc) return rc; }
+            if (part != 2) BH_HIP(c, hipMemsetAsync(c->body_counts, 0, (size_t)std::max<int64_t>(c->n, 1) * sizeof(uint32_t), c->stream));
+            a.body_counts = c->body_counts;
+        }
         // the register-lane stack holds 128 entries and pairs entries only while the bound of
         // walk_tree_asm allows it, so it serves every max_depth <= 32; the LDS stack is the flag's variant
         const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0;
-        a.pair_limit = std::max(0, 120 - 3 * c->Dm);
+        a.pair_limit = std::max(0, 116 - 3 * c->Dm);   // the stack bound of walk_tree_asm2 (bh_walk_fast.hip)
         const int mode = c->let_mode ? 0 : c->walk_mode;
         // few bodies: several waves per 64-body group (bh_walk_fast.hip).  Measured best factor
         // (scripts/split_ab.sh): 8 up to 32k bodies per launch, 4 up to ~100k, one wave
@@ -563,6 +570,11 @@ static int to_caller_order(bh_ctx *c, double *host, int per);
 extern "C" {
 
 int bh_abi_version(void) { return BHGPU_ABI_VERSION; }
+
+#ifndef BHGPU_BUILD_INFO
+#define BHGPU_BUILD_INFO "digest=unknown flags=unknown"
+#endif
+const char *bh_build_info(void) { return BHGPU_BUILD_INFO; }
 
 const char *bh_last_error(const bh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -643,8 +655,10 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     A(&c->keys[0], cap); A(&c->keys[1], cap); A(&c->vals[0], cap); A(&c->vals[1], cap);
     A(&c->cnt, cap + 1);
     { const size_t nbl = std::max<size_t>(blocks_for(cap, kSortTile), blocks_for(std::min<int64_t>(cap, 1 << 22), kBlock * kSmallItems));
-      // (the bucket pass of launches above 1M bodies counts 1,024 buckets per tile)
-      const size_t big = (!c->exact && cap > kBucketMaxN) ? (size_t)kBucketsBig * blocks_for(std::min<int64_t>(cap, kBucketMaxNBig), kSortTile) : 0;
+      // (the bucket pass of launches above 1M bodies counts 1,024 buckets per tile; sized for the SMALLEST tile that
+      // can reach it -- BH_BUILD_ITEMS=2 is honoured up to 4M bodies: 2 words per body, 32 MB at 4M -- ADVICE r2:
+      // sized for kSortTile only, the 512-key tiles of that override wrote past the end between 1M and 4M bodies)
+      const size_t big = (!c->exact && cap > kBucketMaxN) ? (size_t)kBucketsBig * blocks_for(std::min<int64_t>(cap, kBucketMaxNBig), kBlock * kSmallItems) : 0;
       A(&c->radix_counts, std::max<size_t>((size_t)(1 << kSortBits) * nbl, big));
       A(&c->bsum_sort, kBucketsBig + 8);
       A(&c->splitters, kBucketsBig);
@@ -949,6 +963,24 @@ int bh_get_accel(bh_ctx *c, double *out)
         for (int64_t i = 0; i < c->n; ++i) { out[2 * i] /= m[i]; out[2 * i + 1] /= m[i]; }
     }
     return to_caller_order(c, out, 2);
+}
+
+int bh_get_interaction_counts(bh_ctx *c, uint32_t *out)
+{
+    if (!c || !out) return fail(c, BH_ERR_ARG, "bh_get_interaction_counts: null array");
+    if (c->exact || !(c->cfg.flags & BH_FLAG_WALK_STATS) || !c->body_counts)
+        return fail(c, BH_ERR_STATE, "bh_get_interaction_counts: fp32 / mixed precision with BH_FLAG_WALK_STATS, after a walk");
+    BH_HIP(c, hipSetDevice(c->device));
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+    const int64_t n = c->n;
+    if (n == 0) return BH_OK;
+    std::vector<uint32_t> t(n);
+    BH_HIP(c, hipMemcpy(t.data(), c->body_counts, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (c->orig_identity) { std::memcpy(out, t.data(), n * sizeof(uint32_t)); return BH_OK; }
+    std::vector<uint32_t> o(n);
+    BH_HIP(c, hipMemcpy(o.data(), c->orig, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i) out[o[i]] = t[i];
+    return BH_OK;
 }
 
 // ---- tree export: DFS pre-order, children in index order (TraverseTreeToFile, project.cu:504-534)

@@ -45,10 +45,12 @@ struct WalkFastArgs {
     int32_t part;
     float2 *acc_part;
     int64_t forest_base, let_cap;
+    uint32_t *body_counts;         // counting variant (BH_FLAG_WALK_STATS): accepted force evaluations per body, added
+                                   // atomically at the body's device slot (the engine zeroes it); may be null
 };
 
 // mode: 0 = one stack entry per iteration, 1 = software-pipelined, 2 = two entries per iteration.
-// split: 1 = one wave per 64 bodies; 2/4/8/16 = that many waves share each 64-body group (few bodies).
+// split: 1 = one wave per 64 bodies; 2/4/8 = that many waves share each 64-body group (few bodies; more than 8 -> 8).
 // The launch writes one `partial` entry per workgroup: per 256 bodies, or per 64 when split > 1
 // (walk_fast_split_effective tells which applies).
 // use_asm: take the hand-scheduled loop where it applies (32-bit byte offsets into the quad array: the

@@ -104,7 +104,11 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
 #ifndef BH_ASM_EXECZ
 #define BH_ASM_EXECZ 0         // skip the force math of a child that no lane accepts
 #endif
-#if BH_ASM_EXECZ
+#if BH_ASM_EXECZ == 2          // v_rsq stays early (its latency hidden); only the five dependent VALU are skipped
+#define BH_FORCE_HEAD(TAG) "s_cbranch_execz Lskip" TAG "_%=\n"
+#define BH_FORCE_RSQ_EARLY "v_rsq_f32_e32 v25, v24\n"
+#define BH_FORCE_TAIL(TAG) "Lskip" TAG "_%=:\n"
+#elif BH_ASM_EXECZ
 #define BH_FORCE_HEAD(TAG) "s_cbranch_execz Lskip" TAG "_%=\n v_rsq_f32_e32 v25, v24\n s_nop 0\n"
 #define BH_FORCE_RSQ_EARLY ""
 #define BH_FORCE_TAIL(TAG) "Lskip" TAG "_%=:\n"
@@ -130,6 +134,48 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
 #else
 #define BH_PAD_V ""
 #endif
+// round-3 experiments (scripts/walk_ab.sh variants): prefetch of a pushed child's quad (one dword from its first and
+// one from its last 128-byte line: L2 / scalar-cache warm-up, the data go to a dummy register), loads of A issued
+// before B is popped, raised priority between pop and wait, loop alignment
+#ifndef BH_X_PREFETCH
+#define BH_X_PREFETCH 0
+#endif
+#ifndef BH_X_LOADA_FIRST
+#define BH_X_LOADA_FIRST 0
+#endif
+#ifndef BH_X_SETPRIO
+#define BH_X_SETPRIO 0
+#endif
+#ifndef BH_X_ALIGN
+#define BH_X_ALIGN 0
+#endif
+#define BH_STR2(x) #x
+#define BH_STR(x) BH_STR2(x)
+#if BH_X_PREFETCH == 1
+#define BH_PREFETCH(CS) "s_max_i32 s68, " CS ", 0\n s_mul_i32 s68, s68, 0x50\n s_load_dword s72, %[quads], s68\n s_load_dword s72, %[quads], s68 offset:0x4c\n"
+#elif BH_X_PREFETCH == 2
+#define BH_PREFETCH(CS) "s_max_i32 s68, " CS ", 0\n s_mul_i32 s68, s68, 0x50\n s_load_dword s72, %[quads], s68 offset:0x3c\n"
+#else
+#define BH_PREFETCH(CS) ""
+#endif
+#if BH_X_SETPRIO
+#define BH_PRIO_HI "s_setprio " BH_STR(BH_X_SETPRIO) "\n"
+#define BH_PRIO_LO "s_setprio 0\n"
+#else
+#define BH_PRIO_HI ""
+#define BH_PRIO_LO ""
+#endif
+// -DBH_ASM_GUARD=1 (first run of a rewritten loop on hardware): a wave leaves after 2^20 iterations whatever its stack says
+#if defined(BH_ASM_GUARD) && BH_ASM_GUARD
+#define BH_LOOP_GUARD "s_cmp_gt_u32 %[cost], 0x100000\n s_cbranch_scc1 Ldone_%=\n"
+#else
+#define BH_LOOP_GUARD ""
+#endif
+#if BH_X_ALIGN
+#define BH_LOOP_ALIGN ".p2align " BH_STR(BH_X_ALIGN) "\n"
+#else
+#define BH_LOOP_ALIGN ""
+#endif
 #if BH_ASM_PAD_SALU
 #define BH_PAD_S "s_mov_b32 s70, s70\n s_mov_b32 s70, s70\n s_mov_b32 s70, s70\n s_mov_b32 s70, s70\n"
 #else
@@ -137,7 +183,7 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
 #endif
 // PUSHCHK: "" in an iteration that starts with at most 56 entries (two pops, at most eight pushes: every
 // entry it touches sits in lanes of v30..v32), BH_PUSHCHK(TAG) otherwise (entries 64..127 live in v33..v35)
-#define BH_CHILD(XY, MS, TS, CS, MASK, TAG, PUSHCHK)                                                \
+#define BH_CHILD(XY, MS, TS, CS, MASK, TAG, PUSHCHK, PF)                                                \
     "v_pk_add_f32 v[22:23], " XY ", v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n"                           \
     "s_cmp_eq_u32 " MS ", 0\n"                                                                      \
     "s_cbranch_scc1 Lnext" TAG "_%=\n"                                                              \
@@ -155,6 +201,7 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
     "v_writelane_b32 v32, s69, m0\n"                                                                \
     "LpushBack" TAG "_%=:\n"                                                                        \
     "s_add_u32 m0, m0, 1\n"                                                                         \
+    PF                                                                                              \
     "Lforce" TAG "_%=:\n"                                                                           \
     BH_FORCE_HEAD(TAG)                                                                              \
     "v_mul_f32_e32 v26, " MS ", v25\n"                                                              \
@@ -189,9 +236,54 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
     "v_readfirstlane_b32 " IDX ", v33\n v_readfirstlane_b32 " LO ", v34\n v_readfirstlane_b32 " HI ", v35\n" \
     "s_branch LpopBack" TAG "_%=\n"
 // one iteration: entries A (and B), loads, evaluation.  SFX distinguishes the two copies' labels.
+#if BH_X_LOADA_FIRST
 #define BH_ITERATION(SFX, POPA, POPB, CHK)                                                          \
     "s_sub_u32 m0, m0, 1\n"                              /* SCC = borrow: the stack was empty */    \
     "s_cbranch_scc1 Ldone_%=\n"                                                                     \
+    BH_PRIO_HI                                                                                      \
+    POPA                                                                                            \
+    "s_cmp_lt_i32 s68, 0\n"                                                                         \
+    "s_cbranch_scc1 Lspecial_%=\n"                                                                  \
+    "LloadA" SFX "_%=:\n"                                /* s68 = quad index >= 0, s[44:45] = mask */ \
+    "s_mul_i32 s69, s68, 0x50\n"                                                                    \
+    "s_load_dwordx16 s[24:39], %[quads], s69\n"                                                     \
+    "s_load_dwordx4 s[40:43], %[quads], s69 offset:0x40\n"                                          \
+    "s_mov_b32 s71, 0\n"                                 /* s71 != 0: a second quad (B) is in flight */ \
+    "s_cmp_eq_u32 m0, 0\n"                                                                          \
+    "s_cbranch_scc1 LwaitA" SFX "_%=\n"                                                             \
+    "s_cmp_gt_u32 m0, %[plim]\n"                         /* pairs only while the stack bound allows */ \
+    "s_cbranch_scc1 LwaitA" SFX "_%=\n"                                                             \
+    "s_sub_u32 m0, m0, 1\n"                                                                         \
+    POPB                                                                                            \
+    "s_cmp_lt_i32 s70, 0\n"                                                                         \
+    "s_cbranch_scc1 Lunpop" SFX "_%=\n"                                                             \
+    "s_mul_i32 s71, s70, 0x50\n"                         /* (a quad index >= 1: the offset is not 0) */ \
+    "s_load_dwordx16 s[48:63], %[quads], s71\n"                                                     \
+    "s_load_dwordx4 s[64:67], %[quads], s71 offset:0x40\n"                                          \
+    "LwaitA" SFX "_%=:\n"                                                                           \
+    "s_mov_b64 exec, s[44:45]\n"                                                                    \
+    "s_waitcnt lgkmcnt(0)\n"                                                                        \
+    BH_PRIO_LO                                                                                      \
+    BH_CHILD("s[24:25]", "s32", "s36", "s40", "s[44:45]", SFX "A0", CHK(SFX "A0"), BH_PREFETCH("s40"))  \
+    BH_CHILD("s[26:27]", "s33", "s37", "s41", "s[44:45]", SFX "A1", CHK(SFX "A1"), BH_PREFETCH("s41"))  \
+    BH_CHILD("s[28:29]", "s34", "s38", "s42", "s[44:45]", SFX "A2", CHK(SFX "A2"), BH_PREFETCH("s42"))  \
+    BH_CHILD("s[30:31]", "s35", "s39", "s43", "s[44:45]", SFX "A3", CHK(SFX "A3"), BH_PREFETCH("s43"))  \
+    "s_cmp_eq_u32 s71, 0\n"                                                                         \
+    "s_cbranch_scc1 Lloop_%=\n"                                                                     \
+    "s_mov_b64 exec, s[46:47]\n"                                                                    \
+    BH_CHILD("s[48:49]", "s56", "s60", "s64", "s[46:47]", SFX "B0", CHK(SFX "B0"), BH_PREFETCH("s64"))  \
+    BH_CHILD("s[50:51]", "s57", "s61", "s65", "s[46:47]", SFX "B1", CHK(SFX "B1"), BH_PREFETCH("s65"))  \
+    BH_CHILD("s[52:53]", "s58", "s62", "s66", "s[46:47]", SFX "B2", CHK(SFX "B2"), BH_PREFETCH("s66"))  \
+    BH_CHILD("s[54:55]", "s59", "s63", "s67", "s[46:47]", SFX "B3", CHK(SFX "B3"), BH_PREFETCH("s67"))  \
+    "s_branch Lloop_%=\n"                                                                           \
+    "Lunpop" SFX "_%=:\n"                                /* B is a bucket reference: leave it there */ \
+    "s_add_u32 m0, m0, 1\n"                                                                         \
+    "s_branch LwaitA" SFX "_%=\n"
+#else
+#define BH_ITERATION(SFX, POPA, POPB, CHK)                                                          \
+    "s_sub_u32 m0, m0, 1\n"                              /* SCC = borrow: the stack was empty */    \
+    "s_cbranch_scc1 Ldone_%=\n"                                                                     \
+    BH_PRIO_HI                                                                                      \
     POPA                                                                                            \
     "s_cmp_lt_i32 s68, 0\n"                                                                         \
     "s_cbranch_scc1 Lspecial_%=\n"                                                                  \
@@ -213,21 +305,23 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
     "s_load_dwordx4 s[40:43], %[quads], s69 offset:0x40\n"                                          \
     "s_mov_b64 exec, s[44:45]\n"                                                                    \
     "s_waitcnt lgkmcnt(0)\n"                                                                        \
-    BH_CHILD("s[24:25]", "s32", "s36", "s40", "s[44:45]", SFX "A0", CHK(SFX "A0"))                  \
-    BH_CHILD("s[26:27]", "s33", "s37", "s41", "s[44:45]", SFX "A1", CHK(SFX "A1"))                  \
-    BH_CHILD("s[28:29]", "s34", "s38", "s42", "s[44:45]", SFX "A2", CHK(SFX "A2"))                  \
-    BH_CHILD("s[30:31]", "s35", "s39", "s43", "s[44:45]", SFX "A3", CHK(SFX "A3"))                  \
+    BH_PRIO_LO                                                                                      \
+    BH_CHILD("s[24:25]", "s32", "s36", "s40", "s[44:45]", SFX "A0", CHK(SFX "A0"), BH_PREFETCH("s40"))                  \
+    BH_CHILD("s[26:27]", "s33", "s37", "s41", "s[44:45]", SFX "A1", CHK(SFX "A1"), BH_PREFETCH("s41"))                  \
+    BH_CHILD("s[28:29]", "s34", "s38", "s42", "s[44:45]", SFX "A2", CHK(SFX "A2"), BH_PREFETCH("s42"))                  \
+    BH_CHILD("s[30:31]", "s35", "s39", "s43", "s[44:45]", SFX "A3", CHK(SFX "A3"), BH_PREFETCH("s43"))                  \
     "s_cmp_eq_u32 s71, 0\n"                                                                         \
     "s_cbranch_scc1 Lloop_%=\n"                                                                     \
     "s_mov_b64 exec, s[46:47]\n"                                                                    \
-    BH_CHILD("s[48:49]", "s56", "s60", "s64", "s[46:47]", SFX "B0", CHK(SFX "B0"))                  \
-    BH_CHILD("s[50:51]", "s57", "s61", "s65", "s[46:47]", SFX "B1", CHK(SFX "B1"))                  \
-    BH_CHILD("s[52:53]", "s58", "s62", "s66", "s[46:47]", SFX "B2", CHK(SFX "B2"))                  \
-    BH_CHILD("s[54:55]", "s59", "s63", "s67", "s[46:47]", SFX "B3", CHK(SFX "B3"))                  \
+    BH_CHILD("s[48:49]", "s56", "s60", "s64", "s[46:47]", SFX "B0", CHK(SFX "B0"), BH_PREFETCH("s64"))                  \
+    BH_CHILD("s[50:51]", "s57", "s61", "s65", "s[46:47]", SFX "B1", CHK(SFX "B1"), BH_PREFETCH("s65"))                  \
+    BH_CHILD("s[52:53]", "s58", "s62", "s66", "s[46:47]", SFX "B2", CHK(SFX "B2"), BH_PREFETCH("s66"))                  \
+    BH_CHILD("s[54:55]", "s59", "s63", "s67", "s[46:47]", SFX "B3", CHK(SFX "B3"), BH_PREFETCH("s67"))                  \
     "s_branch Lloop_%=\n"                                                                           \
     "Lunpop" SFX "_%=:\n"                                /* B is a bucket reference: leave it there */ \
     "s_add_u32 m0, m0, 1\n"                                                                         \
     "s_branch LloadA" SFX "_%=\n"
+#endif
 #define BH_NOCHK(TAG) ""
 
 // Traversal order (shared with the C++ loop below, bit for bit): the root quad alone; then, as long as
@@ -261,6 +355,7 @@ __device__ __forceinline__ uint32_t walk_tree_asm(const QuadF BH_CONSTANT *quads
         "s_mov_b32 %[cost], 1\n"                                // loop iterations: the group's cost (re-balancing weight)
         "s_branch LloadAF_%=\n"                                 // the root quad alone
         // ---------------------------------------------------------------- next entries
+        BH_LOOP_ALIGN
         "Lloop_%=:\n"
         "s_add_u32 %[cost], %[cost], 1\n"
         "s_cmp_gt_u32 m0, 56\n"
@@ -318,6 +413,283 @@ __device__ __forceinline__ uint32_t walk_tree_asm(const QuadF BH_CONSTANT *quads
         : "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39",
           "s40", "s41", "s42", "s43", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
           "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s69", "s70", "s71",
+#if BH_X_PREFETCH
+          "s72",
+#endif
+          "m0", "vcc", "scc", "memory",
+          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35");
+    return cost;
+}
+// ---- round 3: the same loop with a REGISTER HAND-OFF of the first opened child ---------------------------------
+// Every quad but the root used to be pushed once (three v_writelane, 12.6 cycles of vector issue) and popped once
+// (three v_readfirstlane, 12.3): 25 of the ~138 vector cycles a quad costs, for data that
+// already sit in SGPRs when the next iteration wants them.  Here the FIRST child of A that some lane opens stays
+// in scalar registers and becomes the next iteration's A (NA: index s72, lane mask s[68:69], moved to s[44:45]
+// when A's own mask dies); likewise the first opened child of B becomes the next B (NB: index s70, mask s[68:69]
+// -> s[46:47]).  Only the other opened children go through the VGPR stack.  Which child opens first is only
+// known at run time, so each child block exists in two flavours -- "slot free" (BH_CHILD_F: the open mask is
+// computed straight into the hand-off pair, a taken child costs one s_mov and leaves through BH_TAKE, which
+// carries a copy of the force math and continues in the other chain) and "slot taken" (BH_CHILD_T: the push of
+// the old loop) -- and the program counter remembers the state.
+// Abstract machine (the C++ loop below implements the same one, bit for bit):
+//   A := NA, else the stack's top (a bucket reference is served on the spot and the iteration ends), else NB, else done;
+//   B := NB, else -- if the stack is not empty and holds at most pair_limit entries -- its top (a bucket reference
+//        is left there), else none;
+//   evaluate A: the first opened child that is a quad becomes NA, other opened children are pushed;
+//   evaluate B: likewise with NB, but only if the stack holds at most pair_limit entries when B's evaluation starts.
+// Stack bound: an iteration with a B is entered with at most pair_limit + 3 entries (an NB was taken at
+// <= pair_limit entries and at most 3 pushes followed; a popped B leaves <= pair_limit - 1) and pushes at most 7;
+// from S entries a run of single-quad iterations (depth first: three waiting siblings per level, four at the
+// last) never holds more than S + 3 * Dm + 1; with pair_limit = 116 - 3 * Dm the 128 entries always suffice.
+// Fixed SGPRs as in walk_tree_asm, except: s[68:69] is the hand-off pair (and the open-mask scratch of the
+// "free" flavour), s[70:71] / s[24:25] the open-mask scratch of the "taken" flavour while A / B is evaluated
+// (B's index and offset, resp. quad A, are dead by then), s72 NA's index (-1: none), s70 NB's index between
+// iterations (-1: none), "no B in flight" is s[46:47] == 0.
+#define BH_FORCE_MATH(MS, MASK)                                                                     \
+    "v_mul_f32_e32 v26, " MS ", v25\n"                                                              \
+    "v_mul_f32_e32 v26, v25, v26\n"                                                                 \
+    "v_mul_f32_e32 v24, v25, v26\n"                                                                 \
+    "v_fmac_f32_e32 v28, v24, v22\n"                                                                \
+    "v_fmac_f32_e32 v29, v24, v23\n"                                                                \
+    "s_mov_b64 exec, " MASK "\n"
+#define BH_CHILD_HEAD(XY, MS, TS, MASK, SPAIR, TAG)                                                 \
+    "v_pk_add_f32 v[22:23], " XY ", v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n"                           \
+    "s_cmp_eq_u32 " MS ", 0\n"                                                                      \
+    "s_cbranch_scc1 Lnext" TAG "_%=\n"                                                              \
+    "v_mul_f32_e32 v24, v23, v23\n"                                                                 \
+    "v_fmac_f32_e32 v24, v22, v22\n"                                                                \
+    "v_cmpx_lt_f32_e32 vcc, " TS ", v24\n"                                                          \
+    "v_rsq_f32_e32 v25, v24\n"                                                                      \
+    "s_andn2_b64 " SPAIR ", " MASK ", vcc\n"                                                        \
+    "s_cbranch_scc0 Lforce" TAG "_%=\n"
+// slot taken: opened children (quads and bucket references) are pushed
+#define BH_CHILD_T(XY, MS, TS, CS, MASK, SPAIR, SLO, SHI, TAG, PUSHCHK)                             \
+    BH_CHILD_HEAD(XY, MS, TS, MASK, SPAIR, TAG)                                                     \
+    "s_cmp_eq_u32 " CS ", -1\n"                                                                     \
+    "s_cbranch_scc1 Lforce" TAG "_%=\n"                                                             \
+    PUSHCHK                                                                                         \
+    "v_writelane_b32 v30, " CS ", m0\n"                                                             \
+    "v_writelane_b32 v31, " SLO ", m0\n"                                                            \
+    "v_writelane_b32 v32, " SHI ", m0\n"                                                            \
+    "LpushBack" TAG "_%=:\n"                                                                        \
+    "s_add_u32 m0, m0, 1\n"                                                                         \
+    "Lforce" TAG "_%=:\n"                                                                           \
+    BH_FORCE_MATH(MS, MASK)                                                                         \
+    "Lnext" TAG "_%=:\n"
+// slot free: the open mask lands in the hand-off pair s[68:69]; an opened quad is taken (BH_TAKE, out of line),
+// an opened bucket reference is pushed, an "opened" leaf (the body itself, d2 == 0) is nothing
+#define BH_CHILD_F(XY, MS, TS, CS, MASK, TAG, PUSHCHK)                                              \
+    BH_CHILD_HEAD(XY, MS, TS, MASK, "s[68:69]", TAG)                                                \
+    "s_cmp_gt_i32 " CS ", 0\n"                                                                      \
+    "s_cbranch_scc1 Ltake" TAG "_%=\n"                                                              \
+    "s_cmp_eq_u32 " CS ", -1\n"                                                                     \
+    "s_cbranch_scc1 Lforce" TAG "_%=\n"                                                             \
+    PUSHCHK                                                                                         \
+    "v_writelane_b32 v30, " CS ", m0\n"                                                             \
+    "v_writelane_b32 v31, s68, m0\n"                                                                \
+    "v_writelane_b32 v32, s69, m0\n"                                                                \
+    "LpushBack" TAG "_%=:\n"                                                                        \
+    "s_add_u32 m0, m0, 1\n"                                                                         \
+    "Lforce" TAG "_%=:\n"                                                                           \
+    BH_FORCE_MATH(MS, MASK)                                                                         \
+    "Lnext" TAG "_%=:\n"
+#define BH_TAKE(MS, CS, MASK, NIDX, TAG, NEXT)                                                      \
+    "Ltake" TAG "_%=:\n"                                                                            \
+    "s_mov_b32 " NIDX ", " CS "\n"                                                                  \
+    BH_FORCE_MATH(MS, MASK)                                                                         \
+    "s_branch " NEXT "_%=\n"
+#define BH_PUSH_HI2(CS, SLO, SHI, TAG)                                                              \
+    "LpushHi" TAG "_%=:\n"                                                                          \
+    "v_writelane_b32 v33, " CS ", m0\n"                                                             \
+    "v_writelane_b32 v34, " SLO ", m0\n"                                                            \
+    "v_writelane_b32 v35, " SHI ", m0\n"                                                            \
+    "s_branch LpushBack" TAG "_%=\n"
+#define BH_ITER2(SFX, POPA, POPB, CHK)                                                              \
+    /* ---- A: the handed-over child, else the stack's top, else the handed-over B */               \
+    "s_cmp_gt_i32 s72, -1\n"                                                                        \
+    "s_cbranch_scc1 LAn" SFX "_%=\n"                                                                \
+    "s_sub_u32 m0, m0, 1\n"                              /* SCC = borrow: the stack was empty */    \
+    "s_cbranch_scc1 LAe" SFX "_%=\n"                                                                \
+    POPA                                                                                            \
+    "s_cmp_lt_i32 s68, 0\n"                                                                         \
+    "s_cbranch_scc1 Lspecial_%=\n"                                                                  \
+    "s_branch LAr" SFX "_%=\n"                                                                      \
+    "LAe" SFX "_%=:\n"                                                                              \
+    "s_mov_b32 m0, 0\n"                                                                             \
+    "s_cmp_lt_i32 s70, 0\n"                                                                         \
+    "s_cbranch_scc1 Ldone_%=\n"                                                                     \
+    "s_mov_b32 s68, s70\n"                                                                          \
+    "s_mov_b64 s[44:45], s[46:47]\n"                                                                \
+    "s_mov_b32 s70, -1\n"                                                                           \
+    "s_branch LAr" SFX "_%=\n"                                                                      \
+    "LAn" SFX "_%=:\n"                                                                              \
+    "s_mov_b32 s68, s72\n"                               /* (its mask is in s[44:45] already) */    \
+    "LAr" SFX "_%=:\n"                                   /* s68 = quad index >= 0, s[44:45] = mask */ \
+    "s_mul_i32 s69, s68, 0x50\n"                                                                    \
+    "s_load_dwordx16 s[24:39], %[quads], s69\n"                                                     \
+    "s_load_dwordx4 s[40:43], %[quads], s69 offset:0x40\n"                                          \
+    /* ---- B: the handed-over child, else the stack's top while the stack bound allows pairs */    \
+    "s_cmp_gt_i32 s70, -1\n"                                                                        \
+    "s_cbranch_scc1 LBn" SFX "_%=\n"                                                                \
+    "s_mov_b64 s[46:47], 0\n"                            /* == 0: no B in flight */                 \
+    "s_cmp_eq_u32 m0, 0\n"                                                                          \
+    "s_cbranch_scc1 LW" SFX "_%=\n"                                                                 \
+    "s_cmp_gt_u32 m0, %[plim]\n"                                                                    \
+    "s_cbranch_scc1 LW" SFX "_%=\n"                                                                 \
+    "s_sub_u32 m0, m0, 1\n"                                                                         \
+    POPB                                                                                            \
+    "s_cmp_lt_i32 s70, 0\n"                                                                         \
+    "s_cbranch_scc1 Lunpop" SFX "_%=\n"                                                             \
+    "LBn" SFX "_%=:\n"                                                                              \
+    "s_mul_i32 s71, s70, 0x50\n"                                                                    \
+    "s_load_dwordx16 s[48:63], %[quads], s71\n"                                                     \
+    "s_load_dwordx4 s[64:67], %[quads], s71 offset:0x40\n"                                          \
+    "LW" SFX "_%=:\n"                                                                               \
+    "s_mov_b64 exec, s[44:45]\n"                                                                    \
+    "s_waitcnt lgkmcnt(0)\n"                                                                        \
+    BH_PRIO_LO                                                                                      \
+    /* ---- A's children, hand-off slot free */                                                     \
+    BH_CHILD_F("s[24:25]", "s32", "s36", "s40", "s[44:45]", SFX "A0f", CHK(SFX "A0f"))              \
+    BH_CHILD_F("s[26:27]", "s33", "s37", "s41", "s[44:45]", SFX "A1f", CHK(SFX "A1f"))              \
+    BH_CHILD_F("s[28:29]", "s34", "s38", "s42", "s[44:45]", SFX "A2f", CHK(SFX "A2f"))              \
+    BH_CHILD_F("s[30:31]", "s35", "s39", "s43", "s[44:45]", SFX "A3f", CHK(SFX "A3f"))              \
+    "s_mov_b32 s72, -1\n"                                /* nothing handed over */                  \
+    "s_branch LphB" SFX "_%=\n"                                                                     \
+    /* ---- A's children after one was handed over: the rest is pushed (open masks in s[70:71]) */  \
+    "LA1t" SFX "_%=:\n"                                                                             \
+    BH_CHILD_T("s[26:27]", "s33", "s37", "s41", "s[44:45]", "s[70:71]", "s70", "s71", SFX "A1t", CHK(SFX "A1t")) \
+    "LA2t" SFX "_%=:\n"                                                                             \
+    BH_CHILD_T("s[28:29]", "s34", "s38", "s42", "s[44:45]", "s[70:71]", "s70", "s71", SFX "A2t", CHK(SFX "A2t")) \
+    "LA3t" SFX "_%=:\n"                                                                             \
+    BH_CHILD_T("s[30:31]", "s35", "s39", "s43", "s[44:45]", "s[70:71]", "s70", "s71", SFX "A3t", CHK(SFX "A3t")) \
+    "LAet" SFX "_%=:\n"                                                                             \
+    "s_mov_b64 s[44:45], s[68:69]\n"                     /* NA's mask to its place (A's own is dead) */ \
+    "s_mov_b32 s70, -1\n"                                /* (s70 was scratch; NB is decided below) */ \
+    "LphB" SFX "_%=:\n"                                                                             \
+    "s_cmp_eq_u64 s[46:47], 0\n"                                                                    \
+    "s_cbranch_scc1 Lloop_%=\n"                          /* no B: s70 == -1 here */                 \
+    "s_mov_b64 exec, s[46:47]\n"                                                                    \
+    "s_cmp_gt_u32 m0, %[plim]\n"                         /* too deep for another pair: push everything */ \
+    "s_cbranch_scc1 LBover" SFX "_%=\n"                                                             \
+    BH_CHILD_F("s[48:49]", "s56", "s60", "s64", "s[46:47]", SFX "B0f", CHK(SFX "B0f"))              \
+    BH_CHILD_F("s[50:51]", "s57", "s61", "s65", "s[46:47]", SFX "B1f", CHK(SFX "B1f"))              \
+    BH_CHILD_F("s[52:53]", "s58", "s62", "s66", "s[46:47]", SFX "B2f", CHK(SFX "B2f"))              \
+    BH_CHILD_F("s[54:55]", "s59", "s63", "s67", "s[46:47]", SFX "B3f", CHK(SFX "B3f"))              \
+    "s_mov_b32 s70, -1\n"                                                                           \
+    "s_branch Lloop_%=\n"                                                                           \
+    "LB0t" SFX "_%=:\n"                                                                             \
+    BH_CHILD_T("s[48:49]", "s56", "s60", "s64", "s[46:47]", "s[24:25]", "s24", "s25", SFX "B0t", CHK(SFX "B0t")) \
+    "LB1t" SFX "_%=:\n"                                                                             \
+    BH_CHILD_T("s[50:51]", "s57", "s61", "s65", "s[46:47]", "s[24:25]", "s24", "s25", SFX "B1t", CHK(SFX "B1t")) \
+    "LB2t" SFX "_%=:\n"                                                                             \
+    BH_CHILD_T("s[52:53]", "s58", "s62", "s66", "s[46:47]", "s[24:25]", "s24", "s25", SFX "B2t", CHK(SFX "B2t")) \
+    "LB3t" SFX "_%=:\n"                                                                             \
+    BH_CHILD_T("s[54:55]", "s59", "s63", "s67", "s[46:47]", "s[24:25]", "s24", "s25", SFX "B3t", CHK(SFX "B3t")) \
+    "LBet" SFX "_%=:\n"                                                                             \
+    "s_mov_b64 s[46:47], s[68:69]\n"                     /* NB's mask to its place (garbage if s70 == -1) */ \
+    "s_branch Lloop_%=\n"                                                                           \
+    "Lunpop" SFX "_%=:\n"                                /* B is a bucket reference: leave it there */ \
+    "s_add_u32 m0, m0, 1\n"                                                                         \
+    "s_mov_b32 s70, -1\n"                                                                           \
+    "s_mov_b64 s[46:47], 0\n"                                                                       \
+    "s_branch LW" SFX "_%=\n"                                                                       \
+    "LBover" SFX "_%=:\n"                                /* (s70 may still hold B's own index) */   \
+    "s_mov_b32 s70, -1\n"                                                                           \
+    "s_branch LB0t" SFX "_%=\n"                                                                     \
+    BH_TAKE("s32", "s40", "s[44:45]", "s72", SFX "A0f", "LA1t" SFX)                                 \
+    BH_TAKE("s33", "s41", "s[44:45]", "s72", SFX "A1f", "LA2t" SFX)                                 \
+    BH_TAKE("s34", "s42", "s[44:45]", "s72", SFX "A2f", "LA3t" SFX)                                 \
+    BH_TAKE("s35", "s43", "s[44:45]", "s72", SFX "A3f", "LAet" SFX)                                 \
+    BH_TAKE("s56", "s64", "s[46:47]", "s70", SFX "B0f", "LB1t" SFX)                                 \
+    BH_TAKE("s57", "s65", "s[46:47]", "s70", SFX "B1f", "LB2t" SFX)                                 \
+    BH_TAKE("s58", "s66", "s[46:47]", "s70", SFX "B2f", "LB3t" SFX)                                 \
+    BH_TAKE("s59", "s67", "s[46:47]", "s70", SFX "B3f", "LBet" SFX)
+#define BH_HI_STUBS(SFX)                                                                            \
+    BH_PUSH_HI2("s40", "s68", "s69", SFX "A0f") BH_PUSH_HI2("s41", "s68", "s69", SFX "A1f")          \
+    BH_PUSH_HI2("s42", "s68", "s69", SFX "A2f") BH_PUSH_HI2("s43", "s68", "s69", SFX "A3f")          \
+    BH_PUSH_HI2("s41", "s70", "s71", SFX "A1t") BH_PUSH_HI2("s42", "s70", "s71", SFX "A2t")          \
+    BH_PUSH_HI2("s43", "s70", "s71", SFX "A3t")                                                     \
+    BH_PUSH_HI2("s64", "s68", "s69", SFX "B0f") BH_PUSH_HI2("s65", "s68", "s69", SFX "B1f")          \
+    BH_PUSH_HI2("s66", "s68", "s69", SFX "B2f") BH_PUSH_HI2("s67", "s68", "s69", SFX "B3f")          \
+    BH_PUSH_HI2("s64", "s24", "s25", SFX "B0t") BH_PUSH_HI2("s65", "s24", "s25", SFX "B1t")          \
+    BH_PUSH_HI2("s66", "s24", "s25", SFX "B2t") BH_PUSH_HI2("s67", "s24", "s25", SFX "B3t")
+
+__device__ __forceinline__ uint32_t walk_tree_asm2(const QuadF BH_CONSTANT *quads, const void BH_CONSTANT *consts,
+                                                   int32_t root, uint64_t everyone, int32_t pair_limit, float px,
+                                                   float py, float &ax, float &ay)
+{
+    uint32_t cost;
+    asm volatile(
+        "v_mov_b32_e32 v20, %[px]\n"
+        "v_mov_b32_e32 v21, %[py]\n"
+        "v_mov_b32_e32 v28, %[ax]\n"
+        "v_mov_b32_e32 v29, %[ay]\n"
+        "s_mov_b32 m0, 0\n"                                     // (s68 = root quad, s[44:45] = lane mask: bound operands)
+        "s_mov_b32 s70, -1\n"                                   // no NB
+        "s_mov_b32 s72, -1\n"                                   // no NA
+        "s_mov_b32 %[cost], 1\n"                                // loop iterations: the group's cost (re-balancing weight)
+        "s_branch LArF_%=\n"                                    // the root quad alone
+        // ---------------------------------------------------------------- next entries
+        BH_LOOP_ALIGN
+        "Lloop_%=:\n"
+        "s_add_u32 %[cost], %[cost], 1\n"
+        BH_LOOP_GUARD
+        BH_PRIO_HI
+        "s_cmp_gt_u32 m0, 56\n"
+        "s_cbranch_scc1 LloopChk_%=\n"
+        BH_ITER2("F", BH_POP_FAST("s68", "s44", "s45"), BH_POP_FAST("s70", "s46", "s47"), BH_NOCHK)
+        "LloopChk_%=:\n"                                        // more than 56 entries: pushes / pops pick their VGPRs
+        BH_ITER2("C", BH_POP("s68", "s44", "s45", "A"), BH_POP("s70", "s46", "s47", "B"), BH_PUSHCHK)
+        BH_HI_STUBS("C")
+        BH_POP_HI("s68", "s44", "s45", "A")
+        BH_POP_HI("s70", "s46", "s47", "B")
+        // ---- bucket reference -(node id) - 2: the cell's bodies one by one for the lanes that reached it
+        //      (self and exactly coincident bodies contribute nothing: d2 > 0 fails); -1 is dropped.
+        //      NB (s70, s[46:47]) is preserved; s72 is -1 here.
+        "Lspecial_%=:\n"
+        "s_cmp_eq_u32 s68, -1\n"
+        "s_cbranch_scc1 Lloop_%=\n"
+        "s_load_dwordx8 s[56:63], %[consts], 0x0\n"              // {aux, sorted positions, sorted masses}: this path only
+        "s_sub_i32 s68, -2, s68\n"
+        "s_lshl_b32 s69, s68, 3\n"
+        "s_mov_b64 exec, s[44:45]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_load_dwordx2 s[48:49], s[56:57], s69\n"              // {first sorted body, count}
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_cmp_lt_i32 s49, 1\n"
+        "s_cbranch_scc1 Lloop_%=\n"
+        "s_add_u32 s49, s48, s49\n"
+        "Lbody_%=:\n"
+        "s_lshl_b32 s69, s48, 3\n"
+        "s_load_dwordx2 s[50:51], s[58:59], s69\n"
+        "s_lshl_b32 s69, s48, 2\n"
+        "s_load_dword s52, s[60:61], s69\n"
+        "s_add_u32 s48, s48, 1\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_pk_add_f32 v[22:23], s[50:51], v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n"
+        "s_cmp_lt_u32 s48, s49\n"                         // loop condition (and the packed result's wait state)
+        "v_mul_f32_e32 v24, v23, v23\n"
+        "v_fmac_f32_e32 v24, v22, v22\n"
+        "v_cmpx_lt_f32_e32 vcc, 0, v24\n"
+        "v_rsq_f32_e32 v25, v24\n"
+        "s_nop 0\n"                                             // wait state between v_rsq and its use
+        "v_mul_f32_e32 v26, s52, v25\n"
+        "v_mul_f32_e32 v26, v25, v26\n"
+        "v_mul_f32_e32 v24, v25, v26\n"
+        "v_fmac_f32_e32 v28, v24, v22\n"
+        "v_fmac_f32_e32 v29, v24, v23\n"
+        "s_mov_b64 exec, s[44:45]\n"
+        "s_cbranch_scc1 Lbody_%=\n"
+        "s_branch Lloop_%=\n"
+        "Ldone_%=:\n"
+        "s_mov_b64 exec, -1\n"                                  // (the kernel runs the traversal with all lanes enabled)
+        "v_mov_b32_e32 %[ax], v28\n"
+        "v_mov_b32_e32 %[ay], v29\n"
+        : [ax] "+v"(ax), [ay] "+v"(ay), [cost] "=&s"(cost), "+{s68}"(root), "+{s[44:45]}"(everyone)
+        : [quads] "s"(quads), [consts] "s"(consts), [px] "v"(px), [py] "v"(py), [plim] "s"(pair_limit)
+        : "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39",
+          "s40", "s41", "s42", "s43", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+          "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s69", "s70", "s71", "s72",
           "m0", "vcc", "scc", "memory",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35");
     return cost;
@@ -368,17 +740,17 @@ __device__ __forceinline__ int32_t walk_list_asm(const QuadF BH_CONSTANT *quads,
         "s_load_dwordx4 s[40:43], %[quads], s69 offset:0x40\n"
         "s_mov_b64 exec, s[44:45]\n"
         "s_waitcnt lgkmcnt(0)\n"
-        BH_CHILD("s[24:25]", "s32", "s36", "s40", "s[44:45]", "LA0", "")
-        BH_CHILD("s[26:27]", "s33", "s37", "s41", "s[44:45]", "LA1", "")
-        BH_CHILD("s[28:29]", "s34", "s38", "s42", "s[44:45]", "LA2", "")
-        BH_CHILD("s[30:31]", "s35", "s39", "s43", "s[44:45]", "LA3", "")
+        BH_CHILD("s[24:25]", "s32", "s36", "s40", "s[44:45]", "LA0", "", "")
+        BH_CHILD("s[26:27]", "s33", "s37", "s41", "s[44:45]", "LA1", "", "")
+        BH_CHILD("s[28:29]", "s34", "s38", "s42", "s[44:45]", "LA2", "", "")
+        BH_CHILD("s[30:31]", "s35", "s39", "s43", "s[44:45]", "LA3", "", "")
         "s_cmp_eq_u32 s71, 0\n"
         "s_cbranch_scc1 Lloop_%=\n"
         "s_mov_b64 exec, s[46:47]\n"
-        BH_CHILD("s[48:49]", "s56", "s60", "s64", "s[46:47]", "LB0", "")
-        BH_CHILD("s[50:51]", "s57", "s61", "s65", "s[46:47]", "LB1", "")
-        BH_CHILD("s[52:53]", "s58", "s62", "s66", "s[46:47]", "LB2", "")
-        BH_CHILD("s[54:55]", "s59", "s63", "s67", "s[46:47]", "LB3", "")
+        BH_CHILD("s[48:49]", "s56", "s60", "s64", "s[46:47]", "LB0", "", "")
+        BH_CHILD("s[50:51]", "s57", "s61", "s65", "s[46:47]", "LB1", "", "")
+        BH_CHILD("s[52:53]", "s58", "s62", "s66", "s[46:47]", "LB2", "", "")
+        BH_CHILD("s[54:55]", "s59", "s63", "s67", "s[46:47]", "LB3", "", "")
         "s_branch Lloop_%=\n"
         // ---- bucket reference -(node id) - 2 (see walk_tree_asm); -1 is dropped
         "Lspecial_%=:\n"
@@ -437,6 +809,10 @@ __device__ __forceinline__ int32_t walk_list_asm(const QuadF BH_CONSTANT *quads,
 #undef BH_CHILD
 #undef BH_ITERATION
 
+#ifndef BH_WALK_HANDOFF
+#define BH_WALK_HANDOFF 1      // 0: the round-2 loop (every opened child goes through the VGPR stack), A/B
+#endif
+constexpr bool kHandoff = BH_WALK_HANDOFF != 0;
 constexpr int kLdsStackDepth = 128;   // 3*31+4 entries worst case
 constexpr int kSplitFrontier = 512;   // split walk: frontier entries per level kept in LDS (12 B each, x2)
 constexpr int kSplitRound = 16;       // split walk: quads per wave per round (4 pushes each fill the 64-lane stack)
@@ -487,6 +863,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
     if (a.part == 2 && valid && (SPLIT == 1 || w == 0)) { const float2 t = a.acc_part[s]; ax = t.x; ay = t.y; }
     asm volatile("" : "+v"(ax), "+v"(ay));                // (same for this load: no s_waitcnt vmcnt in the loop)
     unsigned long long n_vis = 0, n_int = 0, n_wave = 0, n_quad = 0;
+    uint32_t my_int = 0;                                     // counting variant: this lane's accepted force evaluations
     uint32_t cost = 0;                                       // loop iterations of this group's walk (re-balancing weight)
 
     const QuadF BH_CONSTANT *quads = as_constant(a.quads);
@@ -497,6 +874,12 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
     int32_t v_base = 0, v_lo = 0, v_hi = 0;      // register-lane stack: entry k lives in lane k & 63 of the
     int32_t v_base2 = 0, v_lo2 = 0, v_hi2 = 0;   // first (k < 64) or second triple: 128 entries (walk_tree_asm)
     int sp = 0;                                   // wave-uniform
+
+    // hand-off slot of the quad being evaluated (walk_tree_asm2): the first opened child that is a quad lands here
+    // instead of on the stack; h_free == false: everything is pushed
+    bool h_free = false;
+    int32_t h_idx = -1;
+    uint64_t h_mask = 0;
 
     auto eval = [&](const float cx, const float cy, const int32_t mbits, const float thr, const int32_t child,
                     const uint64_t mask) {
@@ -521,10 +904,12 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
         const float wgt = __builtin_amdgcn_inverse_ballot_w64(accm) ? m * ri * ri * ri : 0.f;
         ax = fmaf(wgt, dx, ax);
         ay = fmaf(wgt, dy, ay);
-        if (STATS) { n_vis += __popcll(mask); ++n_wave; n_int += __popcll(accm); }
+        if (STATS) { n_vis += __popcll(mask); ++n_wave; n_int += __popcll(accm); my_int += (uint32_t)((accm >> lane) & 1ull); }
         if (child != -1) {                                  // subdivided cell or bucket reference
             const uint64_t open = mask & ~farm;
-            if (open != 0) {                                // ~30 % of the evaluated nodes
+            if (open != 0 && h_free && child > 0) {         // handed over in registers
+                h_idx = child; h_mask = open; h_free = false;
+            } else if (open != 0) {                         // ~30 % of the evaluated nodes
                 if (LDS_STACK) {
                     if (lane == 0) { s_base[w][sp] = child; s_mask[w][sp] = open; }
                 } else if (sp < kWave) {
@@ -566,7 +951,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
             const float wgt = __builtin_amdgcn_inverse_ballot_w64(okm) ? om * ri * ri * ri : 0.f;
             ax = fmaf(wgt, dx, ax);
             ay = fmaf(wgt, dy, ay);
-            if (STATS) n_int += __popcll(okm);
+            if (STATS) { n_int += __popcll(okm); my_int += (uint32_t)((okm >> lane) & 1ull); }
         }
     };
 
@@ -763,7 +1148,49 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
             if (t >= 0 && t == a.self_rank) continue;
             int32_t base = (t < 0) ? 0 : (int32_t)(a.forest_base + (int64_t)t * a.let_cap);
             if (ASM) {
-                cost += walk_tree_asm(quads, as_constant(a.bucket_consts), base, everyone, a.pair_limit, p.x, p.y, ax, ay);
+                cost += kHandoff ? walk_tree_asm2(quads, as_constant(a.bucket_consts), base, everyone, a.pair_limit, p.x, p.y, ax, ay)
+                                 : walk_tree_asm(quads, as_constant(a.bucket_consts), base, everyone, a.pair_limit, p.x, p.y, ax, ay);
+                continue;
+            }
+            if (kHandoff) {
+                // the C++ statement of walk_tree_asm2's abstract machine: same order, same operations
+                int32_t na = -1, nb = -1;                       // handed-over children (quad index, -1: none) ...
+                uint64_t nam = 0, nbm = 0;                      // ... and the lanes that opened them
+                bool first = true;
+                for (;;) {
+                    int32_t bA, bB = -1;
+                    uint64_t mA, mB = 0;
+                    ++cost;
+                    if (first) { bA = base; mA = everyone; first = false; }
+                    else {
+                        if (na >= 0) { bA = na; mA = nam; }
+                        else if (sp > 0) {
+                            pop_raw(bA, mA);
+                            if (bA < 0) {
+                                if (bA <= -2) bucket(-bA - 2, mA);  // -1 (a leaf opened by a NaN) is dropped
+                                continue;
+                            }
+                        } else if (nb >= 0) { bA = nb; mA = nbm; nb = -1; }
+                        else break;
+                        if (nb >= 0) { bB = nb; mB = nbm; }
+                        else if (sp > 0 && sp <= a.pair_limit) {
+                            pop_raw(bB, mB);
+                            if (bB < 0) { ++sp; bB = -1; }          // a bucket reference: leave it on the stack
+                        }
+                    }
+                    const QuadRegs A = load_quad(quads + bA);
+                    const QuadRegs B = load_quad(quads + (bB >= 0 ? bB : 0));
+                    h_free = true; h_idx = -1;
+                    eval_quad(A, mA);
+                    na = h_idx; nam = h_mask;
+                    nb = -1;
+                    if (bB >= 0) {
+                        h_free = sp <= a.pair_limit; h_idx = -1;    // too deep for another pair: push everything
+                        eval_quad(B, mB);
+                        nb = h_idx; nbm = h_mask;
+                    }
+                    h_free = false;
+                }
                 continue;
             }
             // the C++ statement of walk_tree_asm's loop: same order, same operations
@@ -870,6 +1297,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
         if (e.part == 2) e.group_cost[g] += cost;               // the second launch of a split forest walk adds its share
         else e.group_cost[g] = cost;
     }
+    if (STATS && e.body_counts && s < e.hi && my_int) atomicAdd(&e.body_counts[e.perm[s]], my_int);   // (every wave of a split group adds its share)
     if (STATS && lane == 0) {
         atomicAdd(&e.ctr->visits, n_vis);
         atomicAdd(&e.ctr->interactions, n_int);
@@ -913,11 +1341,12 @@ static hipError_t launch_mode(const WalkFastArgs &a, int mode, bool xcd, hipStre
 template <bool S, bool ASM = false>
 static hipError_t launch_split(const WalkFastArgs &a, int split, bool xcd, hipStream_t st)
 {
+    // (16 waves per group was instantiated through round 2: never the measured best at any size, and its
+    // code object spilled 15 SGPRs into VGPR lanes around the assembly blocks; requests above 8 get 8)
     switch (split) {
     case 2: return launch<false, S, 0, 2, ASM>(a, xcd, st);
     case 4: return launch<false, S, 0, 4, ASM>(a, xcd, st);
-    case 8: return launch<false, S, 0, 8, ASM>(a, xcd, st);
-    default: return launch<false, S, 0, 16, ASM>(a, xcd, st);
+    default: return launch<false, S, 0, 8, ASM>(a, xcd, st);
     }
 }
 

@@ -169,6 +169,12 @@ class BarnesHutEngine:
         self._check(self._lib.bh_get_accel(self._h, _dptr(a)))
         return a
 
+    def interaction_counts(self) -> np.ndarray:
+        """Accepted force evaluations per body of the last walk (FLAG_WALK_STATS; fp32 / mixed), caller order."""
+        c = np.zeros(max(self.n, 1), dtype=np.uint32)
+        self._check(self._lib.bh_get_interaction_counts(self._h, c.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return c[:self.n]
+
     # -- tree output ------------------------------------------------------------------------
     def export_tree(self):
         """(nodes in DFS pre-order as TREE_NODE_DTYPE, depth)."""

@@ -222,6 +222,143 @@ void bho_compute_forces(const bho_node *nodes, const double *pos, const double *
     bho_compute_forces_range(nodes, pos, mass, 0, n, theta, G, compat_self_skip, forces, stats);
 }
 
+/* ---- the same walk with per-body diagnostics (test infrastructure of the fp32 parity tests) ----------
+ * Forces are computed by exactly the statements of bho_compute_forces_range (project.cu:593-675) -- the tests
+ * check that they come out bit-identical -- and next to them, per body i:
+ *   counts[i]   accepted force evaluations (the `inter++` of the walk above, per body)
+ *   abs_sum[i]  sum over accepted nodes of |F_j| = G m_i M_j / d_j^2
+ *   coord[i]    sum over accepted CELLS (and, if pr, leaves) of |F_j| * (|comx| + |comy| + pr * (|px| + |py|)) / d_j : how much of the
+ *               force is carried by differences of nearly equal coordinates (a node's centre and a body's
+ *               position are stored as fp32 values on the device: d_j is known to 2^-24 * that sum)
+ *   flip[i]     sum over BORDERLINE subdivided cells of |F(cell accepted) - F(cell opened)|.  A cell is borderline
+ *               for body i when its criterion size/d < theta (project.cu:643) is decided by less than the
+ *               relative uncertainty fp32 arithmetic has about d:  |d - size/theta| <= d * tol,
+ *               tol = 2^-23 * ((|comx| + |comy| + pr * (|px| + |py|)) / d + 4).   An fp32 walk may decide those
+ *               cells, and only those, the other way; each such flip changes the body's force by exactly that
+ *               cell's multipole error, which is what is summed here (F(opened) = the ordinary walk of the
+ *               cell's subtree).  flip[i] == 0: the fp32 walk must accept exactly the oracle's node set.
+ * pr = pos_rounded: 1 when the device rounds the body positions to fp32 itself (mixed precision), 0 when
+ * the inputs already are fp32 values. */
+static void diag_subtree_force(const bho_node *nodes, int64_t start, int64_t i, double px, double py,
+                               double Gmi, double theta, int compat_self_skip, int64_t **stack, int64_t *scap,
+                               double *ofx, double *ofy)
+{
+    /* the walk of bho_compute_forces_range below node `start`, which is treated as opened */
+    double fx = 0.0, fy = 0.0;
+    int64_t top = 0;
+    const bho_node *r = &nodes[start];
+    for (int k = 0; k < 4; ++k) {
+        int64_t ci = (int64_t)r->child[k];
+        if (ci != -1) (*stack)[top++] = ci;
+    }
+    while (top > 0) {
+        const bho_node *q = &nodes[(*stack)[--top]];
+        double qm = q->mass;
+        if (qm <= 1e-15) continue;
+        int64_t occ = (int64_t)q->particle;
+        int leaf = (q->child[0] == -1 && q->child[1] == -1 && q->child[2] == -1 && q->child[3] == -1);
+        double dx = q->comx - px, dy = q->comy - py;
+        double d2 = dx * dx + dy * dy;
+        double d = sqrt(d2) + 1e-15;
+        double ex = q->xmax - q->xmin, ey = q->ymax - q->ymin;
+        double size = (ex > ey) ? ex : ey;
+        if (leaf || (size / d < theta)) {
+            if (leaf) {
+                if (occ == i) continue;
+                if (compat_self_skip && (occ + 2) == -i) continue;
+            }
+            double f = (Gmi * qm) / d2;
+            fx += f * (dx / d);
+            fy += f * (dy / d);
+        } else {
+            if (top + 4 > *scap) {
+                *scap *= 2;
+                *stack = (int64_t *)realloc(*stack, sizeof(int64_t) * (size_t)*scap);
+            }
+            for (int k = 0; k < 4; ++k) {
+                int64_t ci = (int64_t)q->child[k];
+                if (ci != -1) (*stack)[top++] = ci;
+            }
+        }
+    }
+    *ofx = fx; *ofy = fy;
+}
+
+void bho_compute_forces_diag(const bho_node *nodes, const double *pos, const double *mass,
+                             int64_t lo, int64_t hi, double theta, double G, int compat_self_skip,
+                             int pos_rounded, double *forces, uint32_t *counts, double *abs_sum,
+                             double *coord, double *flip)
+{
+    int64_t scap = 1024, *stack = (int64_t *)malloc(sizeof(int64_t) * scap);
+    int64_t scap2 = 1024, *stack2 = (int64_t *)malloc(sizeof(int64_t) * scap2);
+    const double ulp23 = ldexp(1.0, -23);
+    for (int64_t i = lo; i < hi; ++i) {
+        double fx = 0.0, fy = 0.0, asum = 0.0, csum = 0.0, fsum = 0.0;
+        uint32_t cnt = 0;
+        const double px = pos[2 * i], py = pos[2 * i + 1];
+        const double pabs = pos_rounded ? fabs(px) + fabs(py) : 0.0;
+        int64_t top = 0;
+        stack[top++] = 0;
+        while (top > 0) {
+            const int64_t qi = stack[--top];
+            const bho_node *q = &nodes[qi];
+            double qm = q->mass;
+            if (qm <= 1e-15) continue;
+            int64_t occ = (int64_t)q->particle;
+            int leaf = (q->child[0] == -1 && q->child[1] == -1 && q->child[2] == -1 &&
+                        q->child[3] == -1);
+            double dx = q->comx - px;
+            double dy = q->comy - py;
+            double d2 = dx * dx + dy * dy;
+            double d = sqrt(d2) + 1e-15;
+            double ex = q->xmax - q->xmin, ey = q->ymax - q->ymin;
+            double size = (ex > ey) ? ex : ey;
+            const double cabs = fabs(q->comx) + fabs(q->comy) + pabs;
+            if (!leaf) {
+                const double tol = ulp23 * (cabs / d + 4.0);
+                if (fabs(d - size / theta) <= d * tol) {
+                    double f = (G * mass[i] * qm) / d2;
+                    double ax = f * (dx / d), ay = f * (dy / d), ox, oy;
+                    diag_subtree_force(nodes, qi, i, px, py, G * mass[i], theta, compat_self_skip, &stack2,
+                                       &scap2, &ox, &oy);
+                    fsum += sqrt((ax - ox) * (ax - ox) + (ay - oy) * (ay - oy));
+                }
+            }
+            if (leaf || (size / d < theta)) {
+                if (leaf) {
+                    if (occ == i) continue;
+                    if (compat_self_skip && (occ + 2) == -i) continue;
+                }
+                double f = (G * mass[i] * qm) / d2;
+                double ux = dx / d, uy = dy / d;
+                fx += f * ux;
+                fy += f * uy;
+                cnt++;
+                asum += f;
+                /* (a single body's leaf carries that body's position: an exact fp32 value unless the device rounds) */
+                csum += (leaf && !pos_rounded) ? 0.0 : f * (cabs / d);
+            } else {
+                if (top + 4 > scap) {
+                    scap *= 2;
+                    stack = (int64_t *)realloc(stack, sizeof(int64_t) * scap);
+                }
+                for (int k = 0; k < 4; ++k) {
+                    int64_t ci = (int64_t)q->child[k];
+                    if (ci != -1) stack[top++] = ci;
+                }
+            }
+        }
+        forces[2 * i] = fx;
+        forces[2 * i + 1] = fy;
+        if (counts) counts[i] = cnt;
+        if (abs_sum) abs_sum[i] = asum;
+        if (coord) coord[i] = csum;
+        if (flip) flip[i] = fsum;
+    }
+    free(stack);
+    free(stack2);
+}
+
 /* ---- direct sum: main_approach_1.cpp:53-75 ----------------------------------------- */
 void bho_direct_forces(const double *pos, const double *mass, int64_t n, double G,
                        double *forces)

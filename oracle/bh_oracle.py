@@ -70,6 +70,9 @@ def lib() -> C.CDLL:
         L.bho_compute_forces_range.argtypes = [vp, dp, dp, C.c_int64, C.c_int64, C.c_double,
                                                C.c_double, C.c_int, dp, C.POINTER(_WalkStats)]
         L.bho_compute_forces_range.restype = None
+        L.bho_compute_forces_diag.argtypes = [vp, dp, dp, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int,
+                                              C.c_int, dp, C.POINTER(C.c_uint32), dp, dp, dp]
+        L.bho_compute_forces_diag.restype = None
         L.bho_direct_forces.argtypes = [dp, dp, C.c_int64, C.c_double, dp]
         L.bho_direct_forces.restype = None
         L.bho_integrate.argtypes = [dp, dp, C.c_int64, C.c_double, dp, dp, dp]
@@ -137,6 +140,57 @@ def compute_forces(nodes, pos, mass, theta=0.5, G=6.67e-11, compat_self_skip=Tru
     if with_stats:
         return f, WalkStats(st.visits, st.interactions, st.max_stack)
     return f
+
+
+@dataclass
+class WalkDiag:
+    """Per-body diagnostics of the oracle walk (bho_compute_forces_diag); rows outside [lo, hi) are zero."""
+    forces: np.ndarray       # [n, 2], bit-identical to compute_forces
+    counts: np.ndarray       # accepted force evaluations per body
+    abs_sum: np.ndarray      # sum of |F_j| over accepted nodes
+    coord: np.ndarray        # sum of |F_j| * (|comx| + |comy| (+ |px| + |py|)) / d_j
+    flip: np.ndarray         # total multipole error of the borderline cells (0: the node set is unambiguous in fp32)
+
+
+def compute_forces_diag(nodes, pos, mass, theta=0.5, G=6.67e-11, compat_self_skip=True, lo=0, hi=None,
+                        pos_rounded=False, threads=0) -> WalkDiag:
+    """threads > 1: the body range is split over that many Python threads (ctypes releases the GIL; bodies are
+    independent, the results do not depend on the split)."""
+    pos, mass = _f64(pos), _f64(mass)
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    n = pos.shape[0]
+    hi = n if hi is None else hi
+    f = np.zeros((n, 2))
+    cnt = np.zeros(n, dtype=np.uint32)
+    asum, coord, flip = np.zeros(n), np.zeros(n), np.zeros(n)
+    L = lib()
+
+    def run(a, b):
+        L.bho_compute_forces_diag(nodes.ctypes.data, _d(pos), _d(mass), a, b, theta, G, 1 if compat_self_skip else 0,
+                                  1 if pos_rounded else 0, _d(f), cnt.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                  _d(asum), _d(coord), _d(flip))
+    threads = threads or min(16, os.cpu_count() or 1)
+    if threads <= 1 or hi - lo < 4096:
+        run(lo, hi)
+    else:
+        import threading
+        cuts = [lo + (hi - lo) * k // (4 * threads) for k in range(4 * threads + 1)]
+        todo = list(zip(cuts[:-1], cuts[1:]))
+        lock = threading.Lock()
+
+        def work():
+            while True:
+                with lock:
+                    if not todo:
+                        return
+                    a, b = todo.pop()
+                run(a, b)
+        ts = [threading.Thread(target=work) for _ in range(threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    return WalkDiag(f, cnt, asum, coord, flip)
 
 
 def direct_forces(pos, mass, G=6.67e-11) -> np.ndarray:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# (the variants compared here are compiled only into an experiments build: `python -m gpu_nbody_simulation_amd.build --variant exp -DBHGPU_EXPERIMENTS`, then run with BHGPU_LIB=gpu-nbody-simulation_amd/build/libbhgpu_exp.so)
+# (the variants compared here are compiled only into an experiments build: `python -m gpu_nbody_simulation_amd.build --variant exp -DBHGPU_EXPERIMENTS`, then run with BHGPU_LIB_OPT_IN=1 BHGPU_LIB=gpu-nbody-simulation_amd/build/libbhgpu_exp.so)
 # A/B of walk variants in one gpurun call: prints ms_per_step / build / walk for each setting
 for cfg in "0 0" "2 0" "1 0" "0 0" "2 0"; do
   set -- $cfg

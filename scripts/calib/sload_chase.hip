@@ -28,32 +28,70 @@ __global__ __launch_bounds__(256) void chase(const int *buf, uint32_t nrec, int 
 {
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     uint32_t idx = (wave * 2654435761u) % nrec;
+    uint32_t idx2[3] = {idx, (idx * 7u + 1u) % nrec, (idx * 13u + 5u) % nrec};
     int acc = 0;
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
     for (int s = 0; s < steps; ++s) {
-        if (MODE == 0) {
+        if constexpr (MODE == 0) {
             const char CONSTANT *p = (const char CONSTANT *)buf + (size_t)idx * 80;
             const v16i a = *(const v16i CONSTANT *)p;
             const v4i b = *(const v4i CONSTANT *)(p + 64);
             acc += a[3] ^ b[1];
             idx = (uint32_t)a[0] ^ (uint32_t)(b[3] & 0);       // next record; depends on both loads
-        } else if (MODE == 2) {
+        } else if constexpr (MODE == 2) {
             const char CONSTANT *p = (const char CONSTANT *)buf + (size_t)idx * 64;
             const v16i a = *(const v16i CONSTANT *)p;
             acc += a[3] ^ a[9];
             idx = (uint32_t)a[0] ^ (uint32_t)(a[15] & 0);
-        } else if (MODE == 3) {
+        } else if constexpr (MODE == 3) {
             const char CONSTANT *p = (const char CONSTANT *)buf + (size_t)idx * 64;
             const v8i a = *(const v8i CONSTANT *)p;
             const v8i b = *(const v8i CONSTANT *)(p + 32);
             acc += a[3] ^ b[1];
             idx = (uint32_t)a[0] ^ (uint32_t)(b[7] & 0);
-        } else if (MODE == 4) {
+        } else if constexpr (MODE == 4) {
             const char CONSTANT *p = (const char CONSTANT *)buf + (size_t)idx * 128;
             const v16i a = *(const v16i CONSTANT *)p;
             const v4i b = *(const v4i CONSTANT *)(p + 64);
             acc += a[3] ^ b[1];
             idx = (uint32_t)a[0] ^ (uint32_t)(b[3] & 0);
+        } else if constexpr (MODE >= 5 && MODE <= 7) {
+            // round 3 (VERDICT r2 #1a): the 80-byte record through the VECTOR path at a wave-uniform address --
+            // five global_load_dwordx4, every lane the same address, data used in place from VGPRs; MODE - 4
+            // independent chains (records in flight) per wave
+            constexpr int K = MODE - 4;
+            v4i r[K][5];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                uint32_t off = idx2[k] * 80u;
+                asm volatile("" : "+v"(off));              // a VGPR offset: keeps the loads on the vector path
+                const v4i *q = (const v4i *)((const char *)buf + off);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) r[k][j] = q[j];
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const v4i x = r[k][0] ^ r[k][1] ^ r[k][2] ^ r[k][3] ^ r[k][4];     // every dword is consumed (in place, VGPR operands)
+                acc += x[0] ^ x[1] ^ x[2] ^ x[3];
+                idx2[k] = (uint32_t)__builtin_amdgcn_readfirstlane(r[k][0][0] ^ (r[k][4][3] & 0));
+            }
+            s += K - 1;
+        } else if constexpr (MODE == 8 || MODE == 9) {
+            // scalar path, two / three independent chains per wave (what the walk does with its two quads in flight)
+            constexpr int K = MODE - 6;
+            v16i a[K]; v4i b[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const char CONSTANT *p = (const char CONSTANT *)buf + (size_t)idx2[k] * 80;
+                a[k] = *(const v16i CONSTANT *)p;
+                b[k] = *(const v4i CONSTANT *)(p + 64);
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                acc += a[k][3] ^ b[k][1];
+                idx2[k] = (uint32_t)a[k][0] ^ (uint32_t)(b[k][3] & 0);
+            }
+            s += K - 1;
         } else {
             const int lane = threadIdx.x & 63;
             int v = 0;
@@ -66,19 +104,24 @@ __global__ __launch_bounds__(256) void chase(const int *buf, uint32_t nrec, int 
     if ((threadIdx.x & 63) == 0) { out[2 * wave] = t1 - t0; out[2 * wave + 1] = (uint64_t)acc; }
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    // argv[1]: dynamic LDS bytes per workgroup (limits the resident workgroups per CU: 0 -> 8 waves per SIMD,
+    // 27000 -> 6, 40000 -> 4)
+    const unsigned lds = argc > 1 ? (unsigned)atoi(argv[1]) : 0;
     const int blocks = 256 * 8, waves = blocks * 4, steps = 2000;
     uint64_t *d_out;
     hipMalloc(&d_out, sizeof(uint64_t) * 2 * waves);
     std::vector<uint64_t> h(2 * waves);
     std::mt19937 rng(1);
+    printf("dynamic LDS per workgroup: %u bytes\n", lds);
     for (size_t bytes : {size_t(8) << 10, size_t(2) << 20, size_t(60) << 20}) {
         int *d_buf;
         hipMalloc(&d_buf, bytes);
-        const char *names[5] = {"scalar80", "vector80", "s64x16", "s64x8x8", "s128slot"};
-        const int strides[5] = {20, 20, 16, 16, 32};               // dwords per record slot
-        for (int mode = 0; mode < 5; ++mode) {
+        const char *names[10] = {"scalar80", "vector80", "s64x16", "s64x8x8", "s128slot", "vuni80x1", "vuni80x2", "vuni80x3",
+                                 "scalar80x2", "scalar80x3"};
+        const int strides[10] = {20, 20, 16, 16, 32, 20, 20, 20, 20, 20};               // dwords per record slot
+        for (int mode : {0, 1, 5, 6, 7, 8, 9}) {
             const int stride = strides[mode];
             const uint32_t nrec = (uint32_t)(bytes / (4 * stride));
             std::vector<int> host((size_t)nrec * stride);
@@ -92,11 +135,13 @@ int main()
             for (int rep = 0; rep < 2; ++rep) {
                 hipEventRecord(e0);
                 switch (mode) {
-                case 0: hipLaunchKernelGGL(chase<0>, dim3(blocks), dim3(256), 0, 0, d_buf, nrec, steps, d_out); break;
-                case 1: hipLaunchKernelGGL(chase<1>, dim3(blocks), dim3(256), 0, 0, d_buf, nrec, steps, d_out); break;
-                case 2: hipLaunchKernelGGL(chase<2>, dim3(blocks), dim3(256), 0, 0, d_buf, nrec, steps, d_out); break;
-                case 3: hipLaunchKernelGGL(chase<3>, dim3(blocks), dim3(256), 0, 0, d_buf, nrec, steps, d_out); break;
-                default: hipLaunchKernelGGL(chase<4>, dim3(blocks), dim3(256), 0, 0, d_buf, nrec, steps, d_out); break;
+                case 0: hipLaunchKernelGGL(chase<0>, dim3(blocks), dim3(256), lds, 0, d_buf, nrec, steps, d_out); break;
+                case 1: hipLaunchKernelGGL(chase<1>, dim3(blocks), dim3(256), lds, 0, d_buf, nrec, steps, d_out); break;
+                case 5: hipLaunchKernelGGL(chase<5>, dim3(blocks), dim3(256), lds, 0, d_buf, nrec, steps, d_out); break;
+                case 6: hipLaunchKernelGGL(chase<6>, dim3(blocks), dim3(256), lds, 0, d_buf, nrec, steps, d_out); break;
+                case 7: hipLaunchKernelGGL(chase<7>, dim3(blocks), dim3(256), lds, 0, d_buf, nrec, steps, d_out); break;
+                case 8: hipLaunchKernelGGL(chase<8>, dim3(blocks), dim3(256), lds, 0, d_buf, nrec, steps, d_out); break;
+                default: hipLaunchKernelGGL(chase<9>, dim3(blocks), dim3(256), lds, 0, d_buf, nrec, steps, d_out); break;
                 }
                 hipEventRecord(e1);
                 hipDeviceSynchronize();
@@ -107,7 +152,7 @@ int main()
             std::vector<double> cyc;
             for (int w = 0; w < waves; ++w) cyc.push_back((double)h[2 * w] / steps);
             std::sort(cyc.begin(), cyc.end());
-            printf("%-8s buffer %8.2f MB  %7.3f ms  cycles/record/wave median %7.1f (p10 %7.1f p90 %7.1f)  %6.2f G records/s\n",
+            printf("%-10s buffer %8.2f MB  %7.3f ms  cycles/record/wave median %7.1f (p10 %7.1f p90 %7.1f)  %6.2f G records/s\n",
                    names[mode], bytes / 1048576.0, ms, cyc[waves / 2], cyc[waves / 10], cyc[waves * 9 / 10],
                    (double)waves * steps / (ms * 1e-3) * 1e-9);
             hipEventDestroy(e0); hipEventDestroy(e1);

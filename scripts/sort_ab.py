@@ -1,4 +1,4 @@
-"""(the variants compared here are compiled only into an experiments build: `python -m gpu_nbody_simulation_amd.build --variant exp -DBHGPU_EXPERIMENTS`, then run with BHGPU_LIB=gpu-nbody-simulation_amd/build/libbhgpu_exp.so)
+"""(the variants compared here are compiled only into an experiments build: `python -m gpu_nbody_simulation_amd.build --variant exp -DBHGPU_EXPERIMENTS`, then run with BHGPU_LIB_OPT_IN=1 BHGPU_LIB=gpu-nbody-simulation_amd/build/libbhgpu_exp.so)
 build / step ms with the wave-private-ranking scatter (BH_SORT_WAVE_RANK=1, default) and the
 workgroup-ranked one (0).  python scripts/sort_ab.py"""
 import os, sys, time

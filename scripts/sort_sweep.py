@@ -1,4 +1,4 @@
-"""(the variants compared here are compiled only into an experiments build: `python -m gpu_nbody_simulation_amd.build --variant exp -DBHGPU_EXPERIMENTS`, then run with BHGPU_LIB=gpu-nbody-simulation_amd/build/libbhgpu_exp.so)
+"""(the variants compared here are compiled only into an experiments build: `python -m gpu_nbody_simulation_amd.build --variant exp -DBHGPU_EXPERIMENTS`, then run with BHGPU_LIB_OPT_IN=1 BHGPU_LIB=gpu-nbody-simulation_amd/build/libbhgpu_exp.so)
 build ms / step ms with the 3-launch radix pass vs the one-sweep pass (BH_SORT_ONESWEEP) over N."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -9,10 +9,10 @@ PKG=gpu-nbody-simulation_amd
 for lib in $PKG/libbhgpu.so $PKG/build/libbhgpu_*.so; do
   [ -f "$lib" ] || continue
   tag=$(basename $lib .so)
-  BHGPU_LIB=$PWD/$lib timeout -k 10 300 python -m pytest tests/test_gpu_fp32.py -x -q -k "asm_walk or split_walk or bucket_mode" > $OUT/$tag.pytest.log 2>&1
+  BHGPU_LIB_OPT_IN=1 BHGPU_LIB=$PWD/$lib timeout -k 10 300 python -m pytest tests/test_gpu_fp32.py -x -q -k "asm_walk or split_walk or bucket_mode" > $OUT/$tag.pytest.log 2>&1
   echo "$tag pytest rc=$? $(tail -1 $OUT/$tag.pytest.log)"
   for rep in 1 2; do
-    BHGPU_LIB=$PWD/$lib timeout -k 10 200 python bench.py --no-cpu-baseline --no-secondary "$@" > $OUT/$tag.$rep.json 2> $OUT/$tag.err || { echo "$tag bench failed"; tail -3 $OUT/$tag.err; break; }
+    BHGPU_LIB_OPT_IN=1 BHGPU_LIB=$PWD/$lib timeout -k 10 200 python bench.py --no-cpu-baseline --no-secondary "$@" > $OUT/$tag.$rep.json 2> $OUT/$tag.err || { echo "$tag bench failed"; tail -3 $OUT/$tag.err; break; }
     python - <<PY
 import json
 j = json.load(open("$OUT/$tag.$rep.json"))

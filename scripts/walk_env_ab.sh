@@ -1,7 +1,7 @@
 #!/bin/bash
 # walk_ms of the bench workload under environment switches of the experiments build
 # (python -m gpu_nbody_simulation_amd.build --variant exp -DBHGPU_EXPERIMENTS); usage: scripts/walk_env_ab.sh "VAR=val" ...
-export BHGPU_LIB=$PWD/gpu-nbody-simulation_amd/build/libbhgpu_exp.so
+export BHGPU_LIB_OPT_IN=1 BHGPU_LIB=$PWD/gpu-nbody-simulation_amd/build/libbhgpu_exp.so
 for setting in "" "$@"; do
   for rep in 1 2; do
     env $setting python bench.py --no-cpu-baseline --no-secondary 2>/dev/null | python -c "

@@ -1,6 +1,6 @@
 """Per-wave timeline of the last walk launch (experiments build, BH_WALK_TIMELINE): how full are the wave
 slots over the launch, how long is the tail, how do wave durations spread?
-  BHGPU_LIB=.../libbhgpu_exp.so BH_WALK_TIMELINE=/tmp/tl.bin python scripts/walk_timeline.py [n] [init]"""
+  BHGPU_LIB_OPT_IN=1 BHGPU_LIB=.../libbhgpu_exp.so BH_WALK_TIMELINE=/tmp/tl.bin python scripts/walk_timeline.py [n] [init]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

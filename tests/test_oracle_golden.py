@@ -169,3 +169,24 @@ def test_empty_and_single_body():
     assert len(t) == 1 and t["particle"][0] == 0 and t["mass"][0] == 3.0
     f = O.compute_forces(t, np.array([[0.1, 0.2]]), np.array([3.0]))
     assert np.array_equal(f, np.zeros((1, 2)))
+
+
+def test_diagnostic_walk_reproduces_the_pinned_walk(gold):
+    """bho_compute_forces_diag (the fp32 parity tests' per-body diagnostics) restates the pinned walk: forces
+    bit for bit, per-body counts adding up to the walk's own counter -- on the reference's shipped bodies
+    (depth cap 10, the reference's self skip) and on the uncapped tree; any thread split gives the same arrays."""
+    g = gold("ref_project_40960")
+    m, p = g["mass"], g["pos"]
+    for md, compat in ((10, True), (0, False)):
+        t = O.build_tree(p, m, md)
+        f, st = O.compute_forces(t, p, m, compat_self_skip=compat, with_stats=True)
+        d1 = O.compute_forces_diag(t, p, m, compat_self_skip=compat, threads=1)
+        d4 = O.compute_forces_diag(t, p, m, compat_self_skip=compat, threads=4)
+        assert np.array_equal(f, d1.forces) and np.array_equal(f, d4.forces)
+        assert int(d1.counts.sum()) == st.interactions and np.array_equal(d1.counts, d4.counts)
+        for a, b in ((d1.abs_sum, d4.abs_sum), (d1.coord, d4.coord), (d1.flip, d4.flip)):
+            assert np.array_equal(a, b)
+        assert (d1.abs_sum >= np.linalg.norm(f, axis=1) * (1 - 1e-12)).all()      # triangle inequality
+        assert 0 < (d1.flip > 0).mean() < 0.01                                    # borderline cells are rare
+    if md == 10:
+        assert np.array_equal(f, g["forces_0"])                                   # (and the walk itself is the golden one)
