@@ -76,6 +76,8 @@ def parse():
                          "share one GPU together with BHGPU_REHEARSE_ON_DEVICE)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="take the multi-GPU exchange path (step_local, all_gather, scatter) even on one rank")
+    ap.add_argument("--other-configs", default="C2,C4,C5",
+                    help="comma-separated BASELINE configurations for the other_configs leg ('' = none)")
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="bodies walked by the CPU baseline (0 = all, i.e. one full step)")
     return ap.parse_args()
@@ -125,6 +127,16 @@ def cpu_baseline(mass, pos, theta, sample):
     }
 
 
+def _lib_is_product():
+    from gpu_nbody_simulation_amd import _lib
+    return _lib.is_product_library()
+
+
+def _digest():
+    from gpu_nbody_simulation_amd.build import source_digest
+    return source_digest()
+
+
 def rank_churn(p0, p1, depth=16):
     """Fraction of bodies whose rank in the space-filling-curve order, and whose depth-12 cell, changed
     between two consecutive states (host-side, untimed; Morton order on the first state's root box)."""
@@ -150,7 +162,20 @@ def rank_churn(p0, p1, depth=16):
             "median_abs_rank_shift": float(np.median(np.abs(r1 - r0)))}
 
 
-def timed_leg(G, cfg, mass, pos, vel, steps, warmup):
+def spread(x):
+    """p50 / min / max of a per-step series (HIP events per step, bh_step_times)."""
+    x = np.asarray(x, dtype=np.float64)
+    if len(x) == 0:
+        return None
+    return {"p50": float(np.median(x)), "min": float(x.min()), "max": float(x.max()), "steps": int(len(x))}
+
+
+def step_spread(e):
+    st, wk = e.step_times()
+    return {"step_ms": spread(st), "walk_ms": spread(wk)}
+
+
+def timed_leg(G, cfg, mass, pos, vel, steps, warmup, want_state=True):
     """One single-GPU leg: warm-up, K steps enqueued back to back, wall time around them."""
     with G.BarnesHutEngine(cfg) as e:
         e.upload(pos, vel, mass)
@@ -161,13 +186,55 @@ def timed_leg(G, cfg, mass, pos, vel, steps, warmup):
         e.sync()
         dt = time.perf_counter() - t0
         st = e.stats()
-        p0, _ = e.download()
-        e.step(1)
-        p1, _ = e.download()
+        sp = step_spread(e)
+        p0 = p1 = None
+        if want_state:
+            p0, _ = e.download()
+            e.step(1)
+            p1, _ = e.download()
     n = len(mass)
     return {"value": n * steps / dt, "unit": "body-steps/s", "ms_per_step": dt / steps * 1e3, "build_ms": st.build_ms,
             "walk_ms": st.walk_ms, "keys_ms": st.keys_ms, "sort_ms": st.sort_ms, "scan_ms": st.scan_ms,
-            "nodes_ms": st.nodes_ms}, p0, p1
+            "nodes_ms": st.nodes_ms, "per_step": sp}, p0, p1
+
+
+def walk_roofline(G, cfg, mass, pos, vel, walk_ms, stats_flag):
+    """Algorithmic bytes of ONE walk + integrate launch on this state (counting variant of the kernel, untimed)
+    over the measured kernel time: 44 B per body + 20 B per node a wavefront evaluates (DESIGN.md section 6)."""
+    import dataclasses
+    c2 = dataclasses.replace(cfg, flags=cfg.flags | stats_flag)
+    with G.BarnesHutEngine(c2) as se:
+        se.upload(pos, vel, mass)
+        se.compute_forces()
+        ss = se.stats()
+    n = len(mass)
+    b = n * 44 + ss.wave_nodes * NODE_BYTES
+    ach = b / (walk_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "kernel_ms": walk_ms, "algorithmic_bytes_per_launch": b, "u64_nodes_per_body": ss.wave_nodes / n,
+            "interactions_per_body": ss.interactions / n, "n_nodes": ss.n_nodes}
+
+
+def other_configs(G, IC, local, seed, stats_flag, which):
+    """The other BASELINE configurations that fit one GPU (VERDICT r2 #3): not the headline, the same kernels."""
+    out = {}
+    table = {
+        # tag: (kind, n, theta, precision, steps, warmup)
+        "C2": ("uniform", 65536, 0.5, G.Precision.F32, 1000, 20),
+        "C4": ("plummer", 1 << 22, 0.5, G.Precision.F32, 10, 2),
+        "C5": ("plummer", 1 << 24, 0.3, G.Precision.MIXED, 5, 1),
+    }
+    for tag in which:
+        kind, n, theta, prec, steps, warm = table[tag]
+        m, p, v = IC.make(kind, n, seed, quasi_static=True)
+        cfg = G.BhConfig(capacity=n, theta=theta, max_depth=21, precision=prec, reference_compat=False, device=local)
+        leg, _, _ = timed_leg(G, cfg, m, p, v, steps, warm, want_state=False)
+        leg["roofline"] = walk_roofline(G, cfg, m, p, v, leg["walk_ms"], stats_flag)
+        leg["minteractions_per_s"] = leg["roofline"]["interactions_per_body"] * leg["value"] / 1e6
+        out[tag] = {"workload": f"{kind}_N{n}_theta{theta}_{'mixed' if prec == G.Precision.MIXED else 'f32'}", "steps": steps,
+                    "warmup": warm, **leg}
+        del m, p, v
+    return out
 
 
 def main():
@@ -255,6 +322,8 @@ def main():
     for _ in range(a.warmup):
         stepper.step()
     sync_all()
+    if use_let:
+        stepper.profile = True                         # events at the phase boundaries of every timed step
     t0 = time.perf_counter()
     if not sharded:
         eng.step(a.steps)                            # K steps enqueued back to back on one stream
@@ -267,7 +336,25 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    phases = None
     if use_let:
+        stepper.profile = False
+        ph = stepper.phase_ms()
+        lst = eng.stats()
+        ph["let_tree_last_step"], ph["let_pack_last_step"] = lst.let_tree_ms, lst.let_pack_ms
+        keys = sorted(k for k in ph if k != "steps_profiled")
+        t = torch.tensor([ph[k] for k in keys], dtype=torch.float64)
+        tmax, tsum = t.clone(), t.clone()
+        if world > 1:
+            tmax = tmax.to(dev) if a.backend == "nccl" else tmax
+            tsum = tsum.to(dev) if a.backend == "nccl" else tsum
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+            tmax, tsum = tmax.cpu(), tsum.cpu()
+        phases = {"unit": "ms per step, HIP events on each rank's stream, reduced over ranks",
+                  "steps_profiled": ph["steps_profiled"],
+                  "max_over_ranks": {k: float(x) for k, x in zip(keys, tmax)},
+                  "mean_over_ranks": {k: float(x) / world for k, x in zip(keys, tsum)}}
         largest = stepper.check()                    # raises if a LET outgrew its block: run invalid
         let_info = {"let_cap_quads": cap, "largest_let_quads": largest,
                     "all_to_all_bytes_per_rank_per_step": cap * 80 * (world - 1),
@@ -298,6 +385,44 @@ def main():
             dist.all_reduce(red)
             red = red.cpu()
         let_info["net_force_over_sum_abs_force"] = float(max(abs(red[3]), abs(red[4])) / max(float(red[5]), 1e-300))
+        # forces inside each rank's own tree cancel whatever the exchange did, so Newton's third law does
+        # not notice a stale or mis-routed LET.  A DISTRIBUTED DIRECT SUM does: every rank names 64 of its bodies,
+        # the sample positions are all-gathered (W x 64 x 2 doubles), every rank sums the pull of ITS bodies on ALL
+        # samples in fp64 (main_approach_1.cpp:53-75), one all_reduce(SUM) completes the sums, and each rank
+        # compares its own samples with what the forest walk gave them.  Barnes-Hut at theta 0.5 is within ~1e-2 of
+        # the direct sum; a missing or wrong remote tree is off by O(1).
+        ns = 64
+        pick = np.linspace(0, max(len(mf) - 1, 0), ns).astype(np.int64) if len(mf) else np.zeros(ns, dtype=np.int64)
+        mine = torch.tensor(pf[pick] if len(mf) else np.zeros((ns, 2)), dtype=torch.float64)
+        allp = torch.zeros((world, ns, 2), dtype=torch.float64)
+        if world > 1:
+            src = mine.to(dev) if a.backend == "nccl" else mine
+            dst = allp.to(dev) if a.backend == "nccl" else allp
+            dist.all_gather_into_tensor(dst.view(-1), src.view(-1))
+            allp = dst.cpu()
+        else:
+            allp[0] = mine
+        sp = allp.view(-1, 2).numpy()
+        part = np.zeros_like(sp)
+        for c0 in range(0, len(sp), 16):
+            d = pf[None, :, :] - sp[c0:c0 + 16, None, :]
+            r2 = (d * d).sum(2)
+            r2[r2 == 0] = np.inf                                          # the sample itself
+            part[c0:c0 + 16] = (mf[None, :, None] * d / (r2 * np.sqrt(r2))[:, :, None]).sum(1)
+        tot = torch.tensor(part * cfg.G, dtype=torch.float64)
+        if world > 1:
+            tot = tot.to(dev) if a.backend == "nccl" else tot
+            dist.all_reduce(tot)
+            tot = tot.cpu()
+        ref = tot.view(world, ns, 2)[rank].numpy()
+        rerr = np.linalg.norm(acc[pick] - ref, axis=1) / np.linalg.norm(ref, axis=1) if len(mf) else np.zeros(ns)
+        chk = torch.tensor([float(np.median(rerr)), float(rerr.max())], dtype=torch.float64)
+        if world > 1:
+            chk = chk.to(dev) if a.backend == "nccl" else chk
+            dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+            chk = chk.cpu()
+        let_info["direct_sum_check"] = {"samples_per_rank": ns, "worst_rank_median_rel_err": float(chk[0]),
+                                        "max_rel_err": float(chk[1])}
         se.close()
 
         class _S:                                    # the fields the report below reads
@@ -369,6 +494,13 @@ def main():
             "build_groups_ms": {"keys": st.keys_ms, "sort": st.sort_ms, "scan": st.scan_ms, "nodes": st.nodes_ms},
             "roofline": roof,
         }
+        out["library"] = {"build_info": eng.build_info(), "product": _lib_is_product(), "source_digest": _digest()}
+        if not sharded:
+            out["per_step"] = step_spread(eng)
+        out["rccl"] = ({"world_size": dist.get_world_size(), "backend": dist.get_backend()} if dist.is_initialized()
+                       else {"world_size": 1, "backend": None})
+        if phases:
+            out["phases"] = phases
         if let_info:
             out["let"] = let_info
         if world == 1 and not a.no_secondary:
@@ -396,6 +528,15 @@ def main():
                 leg, _, _ = timed_leg(G, cfg_e, me, pe, ve, ks, 2)
                 ex[tag] = {"workload": f"{kind}_N{nn}_theta{a.theta}_depth{md}_exact_fp64", "steps": ks, **leg}
             out["secondary_exact"] = ex
+            # BH_PRECISION_F64: the same fp64 tree, the throughput walk (free order, four siblings per scalar load,
+            # v_rsq_f64 + Newton): the reference's arithmetic TYPE at speed; <= 1e-12 of the oracle, same counts
+            cfg_f = G.BhConfig(capacity=n, theta=a.theta, max_depth=a.max_depth, precision=G.Precision.F64,
+                               reference_compat=True, device=local)
+            leg, _, _ = timed_leg(G, cfg_f, mass, pos, vel, max(5, a.steps // 2), 2, want_state=False)
+            out["secondary_f64"] = {"workload": f"{a.init}_N{n}_theta{a.theta}_depth{a.max_depth}_fast_fp64", **leg}
+        if world == 1 and not a.no_secondary and a.other_configs:
+            out["other_configs"] = other_configs(G, IC, local, a.seed, FLAG_WALK_STATS,
+                                                 [t for t in a.other_configs.split(",") if t])
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(mass, pos, a.theta, a.cpu_sample)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

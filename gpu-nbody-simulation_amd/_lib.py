@@ -49,6 +49,7 @@ class bh_stats_t(C.Structure):
         ("keys_ms", C.c_double), ("sort_ms", C.c_double), ("scan_ms", C.c_double), ("nodes_ms", C.c_double),
         ("build_bytes", C.c_uint64), ("walk_bytes", C.c_uint64), ("wave_quads", C.c_uint64),
         ("sort_spill_buckets", C.c_uint64),
+        ("let_tree_ms", C.c_double), ("let_pack_ms", C.c_double),
     ]
 
 
@@ -87,6 +88,7 @@ SIGNATURES = {
     "bh_get_accel": (C.c_int, [_ctx, _dp]),
     "bh_get_interaction_counts": (C.c_int, [_ctx, C.POINTER(C.c_uint32)]),
     "bh_build_info": (C.c_char_p, []),
+    "bh_step_times": (C.c_int, [_ctx, _dp, _dp, C.c_int32, C.POINTER(C.c_int32)]),
     "bh_export_tree": (C.c_int, [_ctx, _vp, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64)]),
     "bh_write_quadtree_file": (C.c_int, [_ctx, C.c_char_p]),
     "bh_stats": (C.c_int, [_ctx, C.POINTER(bh_stats_t)]),

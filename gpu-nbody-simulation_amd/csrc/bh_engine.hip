@@ -16,6 +16,7 @@
 
 #include "bh_tree.hpp"
 #include "bh_walk_exact.hpp"
+#include "bh_walk_f64.hpp"
 #include "bh_init.hpp"
 #include "bh_let.hpp"
 #include "bh_migrate.hpp"
@@ -38,6 +39,7 @@ struct bh_ctx {
     bh_config cfg{};
     int Dm = 0;
     bool exact = true, compat = true;
+    bool fast64 = false;           // BH_PRECISION_F64: the exact mode's tree and state, the throughput walk of bh_walk_f64.hpp
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -47,7 +49,6 @@ struct bh_ctx {
     int sort_passes = 0;
     bool state64 = false;          // fp64 state arrays: exact and mixed precision
     int walk_split = 0;            // 0 = automatic
-    int walk_mode = 0; bool walk_xcd = false; int walk_order = 0;   // -DBHGPU_EXPERIMENTS builds only (A/B)
     bool walk_asm = true;          // BH_WALK_ASM=0: the C++ loop everywhere (A/B)
     int sort_bucket = 1;           // 1: bucket sort when the previous build's sorted positions are this body set's
                                    // (BH_SORT_BUCKET=0: always the LSD passes; 2: always the bucket sort, tests)
@@ -57,7 +58,7 @@ struct bh_ctx {
     uint16_t *sort_dig = nullptr;  // bucket of every key (written by the histogram, read by the scatter)
     bool sort_wave_rank = true;    // radix_scatter_w (wave-private ranking); experiments: BH_SORT_WAVE_RANK=0
     int build_items = 0;           // 0 = automatic, else keys per thread in the sort / scan kernels (2, 4, 8)
-    bool hilbert = false;                // fp32 mode: Hilbert-ordered keys (BH_HILBERT=0 disables, A/B)  // BH_WALK_PIPE / BH_WALK_XCD override (A/B)
+    bool hilbert = false;                // fp32 mode: Hilbert-ordered keys (BH_HILBERT=0 disables, A/B)
     int partial_count = 0;         // > 0: partial[] holds per-workgroup min/max of the current positions
 
     // state (double2/double or float2/float).  Exact mode: caller order.  fp32 / mixed: DEVICE order --
@@ -129,6 +130,8 @@ struct bh_ctx {
     std::vector<hipEvent_t> ev;        // pairs around the walk kernel, one pair per step
     hipEvent_t ev_step[2] = {nullptr, nullptr}, ev_build[2] = {nullptr, nullptr};
     hipEvent_t ev_grp[3] = {nullptr, nullptr, nullptr};   // after keys / sort / scan of the last timed build
+    hipEvent_t ev_let[3] = {nullptr, nullptr, nullptr};   // bh_let_build: start, local tree built, LETs packed
+    bool let_timed = false;
     bool time_groups = false;      // set by bh_step around its last build
     int64_t steps_done = 0;
     int32_t last_nsteps = 0;
@@ -475,7 +478,19 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
     const bool want_partial = integrate && !to_sorted && lo == 0 && hi == c->n;
     double *partial = want_partial ? c->partial : nullptr;
     int per_partial = kBlock;
-    if (c->exact) {
+    if (c->exact && c->fast64) {
+        const unsigned grid = blocks_for(hi - lo, kBlock);
+        if (stats && !c->body_counts) { int rc = dev_alloc(c, &c->body_counts, (size_t)std::max<int64_t>(c->cfg.capacity, 1)); if (rc) return rc; }
+        auto args = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, c->stream, c->gd, c->ld, c->perm,
+                               (double2 *)c->pos, (double2 *)c->vel, (const double *)c->mass,
+                               (double2 *)c->force, lo, hi, c->cfg.theta, c->cfg.G, c->cfg.dt,
+                               integrate ? 1 : 0, c->ctr, partial, stats ? c->body_counts : nullptr);
+        };
+        if (c->compat) { if (stats) args(walk_f64_kernel<true, true>); else args(walk_f64_kernel<true, false>); }
+        else           { if (stats) args(walk_f64_kernel<false, true>); else args(walk_f64_kernel<false, false>); }
+        BH_HIP(c, hipGetLastError());
+    } else if (c->exact) {
         const unsigned grid = blocks_for(hi - lo, kBlock);
         auto args = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, c->stream, c->gd, c->ld, c->perm,
@@ -498,7 +513,6 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         a.n_trees = c->let_mode ? c->world : 0; a.self_rank = c->let_mode ? c->rank : -1;
         a.part = part; a.acc_part = c->acc_part;
         a.forest_base = c->forest_base; a.let_cap = c->let_cap;
-        a.order_mode = c->walk_order;
 #ifdef BHGPU_EXPERIMENTS
         a.timeline = c->timeline;
 #endif
@@ -514,7 +528,6 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         // walk_tree_asm allows it, so it serves every max_depth <= 32; the LDS stack is the flag's variant
         const bool lds = (c->cfg.flags & BH_FLAG_LDS_STACK) != 0;
         a.pair_limit = std::max(0, 116 - 3 * c->Dm);   // the stack bound of walk_tree_asm2 (bh_walk_fast.hip)
-        const int mode = c->let_mode ? 0 : c->walk_mode;
         // few bodies: several waves per 64-body group (bh_walk_fast.hip).  Measured best factor
         // (scripts/split_ab.sh): 8 up to 32k bodies per launch, 4 up to ~100k, one wave
         // per group -- the hand-scheduled loop with two quads in flight -- beyond (round 1's compiled loop
@@ -535,8 +548,8 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         const int64_t forest_quads = c->let_mode ? c->forest_base + (int64_t)c->world * c->let_cap : c->internal_cap + 1;
         const bool use_asm = c->walk_asm && !(c->cfg.flags & BH_FLAG_WALK_PORTABLE) &&
                              forest_quads * (int64_t)sizeof(QuadF) < (1ll << 31) && c->n < (1ll << 28);
-        BH_HIP(c, launch_walk_fast(a, lds, stats, mode, c->walk_xcd, split, use_asm, c->stream));
-        if (walk_fast_split_effective(a, lds, mode, split)) per_partial = kWave;
+        BH_HIP(c, launch_walk_fast(a, lds, stats, split, use_asm, c->stream));
+        if (walk_fast_split_effective(a, lds, split)) per_partial = kWave;
     }
     if (want_partial) c->partial_count = (int)blocks_for(hi - lo, per_partial);
     if (!c->exact && lo == 0 && hi == c->n) c->group_cost_valid = true;
@@ -588,7 +601,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
         return fail(nullptr, BH_ERR_ARG, "bh_create: max_depth must be 1..32");
     if (!(cfg->theta > 0.0)) return fail(nullptr, BH_ERR_ARG, "bh_create: theta must be > 0");
     if (cfg->precision != BH_PRECISION_F64_EXACT && cfg->precision != BH_PRECISION_F32 &&
-        cfg->precision != BH_PRECISION_MIXED)
+        cfg->precision != BH_PRECISION_MIXED && cfg->precision != BH_PRECISION_F64)
         return fail(nullptr, BH_ERR_ARG, "bh_create: unknown precision");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -599,16 +612,14 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     bh_ctx *c = new bh_ctx();
     c->cfg = *cfg;
     c->Dm = cfg->max_depth - 1;
-    c->exact = cfg->precision == BH_PRECISION_F64_EXACT;
+    c->fast64 = cfg->precision == BH_PRECISION_F64;
+    c->exact = cfg->precision == BH_PRECISION_F64_EXACT || c->fast64;   // (same state, same build)
     c->state64 = c->exact || cfg->precision == BH_PRECISION_MIXED;
     c->compat = cfg->reference_compat != 0;
     c->device = cfg->device;
     c->sort_passes = (2 * c->Dm + kRadixBits - 1) / kRadixBits;
 #ifdef BHGPU_EXPERIMENTS
     // measured-and-rejected variants: present only in scripts/ A/B builds
-    if (const char *e = std::getenv("BH_WALK_PIPE")) c->walk_mode = std::atoi(e);
-    if (const char *e = std::getenv("BH_WALK_XCD")) c->walk_xcd = std::atoi(e) != 0;
-    if (const char *e = std::getenv("BH_WALK_ORDER")) c->walk_order = std::atoi(e);
     if (const char *e = std::getenv("BH_SORT_WAVE_RANK")) c->sort_wave_rank = std::atoi(e) != 0;
     if (const char *e = std::getenv("BH_SORT_ONESWEEP")) c->sort_onesweep = std::atoi(e) != 0;
 #endif
@@ -703,6 +714,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     for (auto &e : c->ev_step) if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(BH_ERR_DEVICE); }
     for (auto &e : c->ev_build) if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(BH_ERR_DEVICE); }
     for (auto &e : c->ev_grp) if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(BH_ERR_DEVICE); }
+    for (auto &e : c->ev_let) if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(BH_ERR_DEVICE); }
     *out = c;
     return BH_OK;
 }
@@ -726,6 +738,7 @@ void bh_destroy(bh_ctx *c)
     for (auto e : c->ev_step) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev_build) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev_grp) if (e) (void)hipEventDestroy(e);
+    for (auto e : c->ev_let) if (e) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -968,8 +981,8 @@ int bh_get_accel(bh_ctx *c, double *out)
 int bh_get_interaction_counts(bh_ctx *c, uint32_t *out)
 {
     if (!c || !out) return fail(c, BH_ERR_ARG, "bh_get_interaction_counts: null array");
-    if (c->exact || !(c->cfg.flags & BH_FLAG_WALK_STATS) || !c->body_counts)
-        return fail(c, BH_ERR_STATE, "bh_get_interaction_counts: fp32 / mixed precision with BH_FLAG_WALK_STATS, after a walk");
+    if ((c->exact && !c->fast64) || !(c->cfg.flags & BH_FLAG_WALK_STATS) || !c->body_counts)
+        return fail(c, BH_ERR_STATE, "bh_get_interaction_counts: fp32 / mixed / BH_PRECISION_F64 with BH_FLAG_WALK_STATS, after a walk");
     BH_HIP(c, hipSetDevice(c->device));
     BH_HIP(c, hipStreamSynchronize(c->stream));
     const int64_t n = c->n;
@@ -1139,6 +1152,11 @@ int bh_stats(bh_ctx *c, bh_stats_t *out)
         out->wave_nodes = h.wave_nodes;
         out->wave_quads = h.wave_quads;
     }
+    if (c->let_timed) {
+        float ms = 0.f;
+        BH_HIP(c, hipEventElapsedTime(&ms, c->ev_let[0], c->ev_let[1])); out->let_tree_ms = ms;
+        BH_HIP(c, hipEventElapsedTime(&ms, c->ev_let[1], c->ev_let[2])); out->let_pack_ms = ms;
+    }
     if (c->step_timed) {
         float ms = 0.f;
         BH_HIP(c, hipEventElapsedTime(&ms, c->ev_step[0], c->ev_step[1]));
@@ -1167,6 +1185,23 @@ int bh_stats(bh_ctx *c, bh_stats_t *out)
         const uint64_t prep_b = c->state64 ? 76u : 40u, scan_b = c->state64 ? 59u : 47u, nodes_b = c->exact ? 140u : 117u;
         out->build_bytes = (uint64_t)c->n * (keys_b + sort_b + prep_b + scan_b + nodes_b);
         out->walk_bytes = out->wave_nodes ? (uint64_t)c->n * 44u + out->wave_nodes * 20u : 0u;
+    }
+    return BH_OK;
+}
+
+int bh_step_times(bh_ctx *c, double *step_ms, double *walk_ms, int32_t cap, int32_t *n_out)
+{
+    if (!c || !n_out) return fail(c, BH_ERR_ARG, "bh_step_times: null argument");
+    BH_HIP(c, hipSetDevice(c->device));
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+    const int n = c->step_timed ? c->timed_pairs : 0;
+    *n_out = n;
+    if (cap < n) return (step_ms || walk_ms) ? fail(c, BH_ERR_CAPACITY, "bh_step_times: buffer too small") : BH_OK;
+    for (int s = 0; s < n; ++s) {
+        float ms = 0.f;
+        if (walk_ms) { BH_HIP(c, hipEventElapsedTime(&ms, c->ev[2 * s], c->ev[2 * s + 1])); walk_ms[s] = ms; }
+        // a step ends where its walk ends; the first one starts where bh_step started
+        if (step_ms) { BH_HIP(c, hipEventElapsedTime(&ms, s ? c->ev[2 * s - 1] : c->ev_step[0], c->ev[2 * s + 1])); step_ms[s] = ms; }
     }
     return BH_OK;
 }
@@ -1346,10 +1381,12 @@ int bh_let_build(bh_ctx *c)
     if (!c->uploaded) return fail(c, BH_ERR_STATE, "bh_let_build before bh_upload");
     BH_HIP(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    (void)hipEventRecord(c->ev_let[0], st);
     hipLaunchKernelGGL(let_box_kernel, dim3(1), dim3(64), 0, st, c->all_bounds, c->world * kLetBoxes, c->box, c->ctr,
                        c->let_ctr, c->Dm);
     int rc = enqueue_build(c);
     if (rc) return rc;
+    (void)hipEventRecord(c->ev_let[1], st);
     const int64_t nq = c->quads_local;
     const int ntiles = (int)blocks_for(nq, kTile);
     hipLaunchKernelGGL(let_mark_kernel, dim3(blocks_for(nq, kBlock)), dim3(kBlock), 0, st, c->qf, c->all_bounds,
@@ -1363,6 +1400,8 @@ int bh_let_build(bh_ctx *c)
     hipLaunchKernelGGL(let_pack_kernel, dim3(blocks_for(nq, kBlock)), dim3(kBlock), 0, st, c->qf, c->needmask,
                        c->let_outidx, nq, c->world, c->rank, c->ctr, c->internal_cap, c->let_send,
                        (uint32_t)c->let_cap, c->forest_base + (int64_t)c->rank * c->let_cap);
+    (void)hipEventRecord(c->ev_let[2], st);
+    c->let_timed = true;
     BH_HIP(c, hipGetLastError());
     return BH_OK;
 }

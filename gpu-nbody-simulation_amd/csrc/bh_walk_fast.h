@@ -28,13 +28,12 @@ struct WalkFastArgs {
     int64_t lo, hi;            // sorted range walked by this launch
     float G, dt;
     int integrate, to_sorted;
-    uint32_t nblocks, xcd_chunk;   // filled by the launcher
+    uint32_t nblocks, pad0;        // nblocks: filled by the launcher
     const void *bucket_consts;     // device block {aux, spos, smass, 0}: the assembly loop's bucket path reads its pointers here
     uint32_t *group_cost;          // per 64-body group: loop iterations of its walk (load-balancing weight), may be null
     int32_t pair_limit;            // one-wave walk: two stack entries per iteration while sp <= pair_limit
                                    // (120 - 3 * (max_depth - 1), never negative: the 128-entry stack bound)
-    uint64_t *timeline;            // experiments: per-wave {start, end, hw id, cost}
-    int32_t order_mode;            // experiment (BH_WALK_ORDER): 0 = blocks in sorted order, 1 = reversed, 2 = strided
+    uint64_t *timeline;            // -DBHGPU_EXPERIMENTS builds: per-wave {start, end, hw id, cost} (scripts/walk_timeline.py)
     // forest walk (distributed step): besides the local tree (root quad 0) the bodies walk the
     // locally-essential trees received from the peers, whose root quads sit at
     // forest_base + t * let_cap for every t != self_rank, t < n_trees.  n_trees == 0: local tree only.
@@ -49,17 +48,15 @@ struct WalkFastArgs {
                                    // atomically at the body's device slot (the engine zeroes it); may be null
 };
 
-// mode: 0 = one stack entry per iteration, 1 = software-pipelined, 2 = two entries per iteration.
 // split: 1 = one wave per 64 bodies; 2/4/8 = that many waves share each 64-body group (few bodies; more than 8 -> 8).
 // The launch writes one `partial` entry per workgroup: per 256 bodies, or per 64 when split > 1
 // (walk_fast_split_effective tells which applies).
 // use_asm: take the hand-scheduled loop where it applies (32-bit byte offsets into the quad array: the
 // caller checks that the forest is smaller than 2 GiB and the bodies fewer than 2^28).
-hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, int mode, bool xcd, int split,
-                            bool use_asm, hipStream_t st);
-inline bool walk_fast_split_effective(const WalkFastArgs &a, bool lds_stack, int mode, int split)
+hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, int split, bool use_asm, hipStream_t st);
+inline bool walk_fast_split_effective(const WalkFastArgs &a, bool lds_stack, int split)
 {
-    return split > 1 && !lds_stack && mode == 0 && a.n_trees <= 56;
+    return split > 1 && !lds_stack && a.n_trees <= 56;
 }
 
 }  // namespace bh

@@ -23,7 +23,6 @@
 //   * epilogue: a = G*sum, v += a*dt, p += v*dt written back in caller order (scatter through
 //     perm), or into the sorted arrays for the multi-GPU exchange; plus the per-workgroup min/max of
 //     the new positions for the next step's root box.
-//   * BH_WALK_PIPE / BH_WALK_XCD select measured-and-rejected loop variants.
 //   * SPLIT > 1 (few bodies: N <= 192k on one GPU, or one rank's share of a multi-GPU run).  The
 //     walk of a 64-body group is a dependent chain of ~200 quad visits; a lone wave spends ~370
 //     cycles waiting for each quad and ~1000 issuing its evaluation (measured with s_memtime),
@@ -76,375 +75,66 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
 }
 
 // ---- hand-scheduled traversal of ONE tree (the default path: register-lane stack, no counters) -------
-// Why assembly: measured on MI355X (scripts/calib/issue_calib.hip, 8 waves per SIMD) a SIMD spends ~4.2
-// cycles per SCALAR instruction, ~2.2 per plain fp32 VALU instruction, ~4.2 per VALU instruction that
-// writes an SGPR pair or reads one as a lane mask (v_cmp, v_cndmask), ~8.3 per v_rsq_f32 / v_readlane_b32;
-// the scalar and the vector stream of different waves overlap.  The compiler's loop (round 1) issued per
-// child 10 VALU + 5 SALU + 3 branches and per quad ~20 more scalar instructions of pop / address / loop
-// control, which made the scalar stream as long as the vector stream.  This loop:
-//   * EXEC holds the stack entry's lane mask for the whole quad and v_cmpx narrows it to the accepting
-//     lanes: no v_cndmask, no s_and of the ballot with the mask, the force math runs under EXEC;
+// Why assembly, and what bounds it.  Measured on MI355X (scripts/calib/issue_calib.hip, 8 waves per SIMD) a SIMD
+// spends ~4.2 cycles per SCALAR instruction, ~2.2 per plain fp32 VALU instruction, ~4.2 per VALU instruction with an
+// SGPR operand or an SGPR-pair result (v_cmp), ~8.3 per v_rsq_f32 / v_readlane_b32; the scalar and the vector
+// stream of different waves overlap.  PMC of the loop (profiles/r03_*): the vector pipe is busy ~91 % and the
+// scalar side ~80-90 % of the kernel's cycles -- BOTH issue streams are nearly full, so an instruction removed
+// from one of them returns about a third of its cost, and an instruction added to the fuller one costs all of
+// it (round 3: hoisting the four children's distance / rsqrt math in front of the per-child logic for ILP spent
+// +12 % vector instructions on empty children and took +12 % time; a register hand-off that removed 6 % of the
+// vector instructions for 6 % more scalar ones returned 2 %).  The loop is therefore written for the fewest
+// instructions of BOTH kinds:
+//   * EXEC holds the entry's lane mask for the whole quad and v_cmpx narrows it to the accepting lanes: no
+//     v_cndmask, no s_and of the ballot with the mask, the force math runs under EXEC;
 //   * `open = mask & ~vcc` sets SCC, which is the push decision: 1 SALU + 1 branch for the ~70 % of the
 //     children nobody opens; the leaf test (child == -1) is only reached by the rest;
-//   * the stack pointer lives in m0 (the lane select of v_readlane / v_writelane), the quad address is one
-//     s_mul_i32 feeding the SGPR-offset form of s_load (round 1: s_mul, s_mul_hi, s_add, s_addc);
-//   * pop is s_sub + branch + three v_readlane.
-// Same operations in the same order as eval()/pop_quad() below, so results are bit-identical to the C++
-// loop (tests/test_gpu_fp32.py::test_asm_walk_equals_the_portable_walk).
-// Hazards handled by instruction order (the assembler does not insert wait states into inline assembly):
-// the consumer of v_rsq_f32 (trans) is separated from it by the scalar push logic; the consumer of
-// v_pk_add_f32 (packed) by the empty-cell test; m0 is written at least one instruction before a lane
-// select uses it.
-// Fixed SGPRs: s[24:43] quad A, s[44:45] its lane mask, s[46:47] B's mask, s[48:67] quad B, s68 / s69 A's quad
-// index and byte offset and, once its loads are issued, the open-mask scratch pair, s70 B's index, s71 B's
-// offset and then the flag "B is in flight".  (The block sits right above the ~24 SGPRs the compiler keeps
-// live across the loop.)
-// Fixed VGPRs (the two-dword operands of v_pk_add_f32 need named halves): v[20:21] body position,
-// v[22:23] dx,dy, v24 d2 then w, v25 1/d, v26 scratch, v[28:29] acceleration sums, v30..v32 the stack.
-#ifndef BH_ASM_EXECZ
-#define BH_ASM_EXECZ 0         // skip the force math of a child that no lane accepts
-#endif
-#if BH_ASM_EXECZ == 2          // v_rsq stays early (its latency hidden); only the five dependent VALU are skipped
-#define BH_FORCE_HEAD(TAG) "s_cbranch_execz Lskip" TAG "_%=\n"
-#define BH_FORCE_RSQ_EARLY "v_rsq_f32_e32 v25, v24\n"
-#define BH_FORCE_TAIL(TAG) "Lskip" TAG "_%=:\n"
-#elif BH_ASM_EXECZ
-#define BH_FORCE_HEAD(TAG) "s_cbranch_execz Lskip" TAG "_%=\n v_rsq_f32_e32 v25, v24\n s_nop 0\n"
-#define BH_FORCE_RSQ_EARLY ""
-#define BH_FORCE_TAIL(TAG) "Lskip" TAG "_%=:\n"
-#else
-#define BH_FORCE_HEAD(TAG) ""
-#define BH_FORCE_RSQ_EARLY "v_rsq_f32_e32 v25, v24\n"
-#define BH_FORCE_TAIL(TAG) ""
-#endif
-// v_pk_add_f32 sits ABOVE the empty-cell test: the two scalar instructions of the test are the wait
-// state a packed result needs before it is read (an empty child wastes those 4 cycles)
-// (-DBHGPU_EXPERIMENTS -DBH_ASM_PAD_VALU=1 / -DBH_ASM_PAD_SALU=1: four redundant vector / scalar
-// instructions per child, the sensitivity experiment of DESIGN.md section 6)
-#if !defined(BHGPU_EXPERIMENTS) || !defined(BH_ASM_PAD_VALU)
-#undef BH_ASM_PAD_VALU
-#define BH_ASM_PAD_VALU 0
-#endif
-#if !defined(BHGPU_EXPERIMENTS) || !defined(BH_ASM_PAD_SALU)
-#undef BH_ASM_PAD_SALU
-#define BH_ASM_PAD_SALU 0
-#endif
-#if BH_ASM_PAD_VALU
-#define BH_PAD_V "v_mov_b32_e32 v27, v27\n v_mov_b32_e32 v27, v27\n v_mov_b32_e32 v27, v27\n v_mov_b32_e32 v27, v27\n"
-#else
-#define BH_PAD_V ""
-#endif
-// round-3 experiments (scripts/walk_ab.sh variants): prefetch of a pushed child's quad (one dword from its first and
-// one from its last 128-byte line: L2 / scalar-cache warm-up, the data go to a dummy register), loads of A issued
-// before B is popped, raised priority between pop and wait, loop alignment
-#ifndef BH_X_PREFETCH
-#define BH_X_PREFETCH 0
-#endif
-#ifndef BH_X_LOADA_FIRST
-#define BH_X_LOADA_FIRST 0
-#endif
-#ifndef BH_X_SETPRIO
-#define BH_X_SETPRIO 0
-#endif
-#ifndef BH_X_ALIGN
-#define BH_X_ALIGN 0
-#endif
-#define BH_STR2(x) #x
-#define BH_STR(x) BH_STR2(x)
-#if BH_X_PREFETCH == 1
-#define BH_PREFETCH(CS) "s_max_i32 s68, " CS ", 0\n s_mul_i32 s68, s68, 0x50\n s_load_dword s72, %[quads], s68\n s_load_dword s72, %[quads], s68 offset:0x4c\n"
-#elif BH_X_PREFETCH == 2
-#define BH_PREFETCH(CS) "s_max_i32 s68, " CS ", 0\n s_mul_i32 s68, s68, 0x50\n s_load_dword s72, %[quads], s68 offset:0x3c\n"
-#else
-#define BH_PREFETCH(CS) ""
-#endif
-#if BH_X_SETPRIO
-#define BH_PRIO_HI "s_setprio " BH_STR(BH_X_SETPRIO) "\n"
-#define BH_PRIO_LO "s_setprio 0\n"
-#else
-#define BH_PRIO_HI ""
-#define BH_PRIO_LO ""
-#endif
-// -DBH_ASM_GUARD=1 (first run of a rewritten loop on hardware): a wave leaves after 2^20 iterations whatever its stack says
+//   * the stack pointer lives in m0 (the lane select of v_writelane, the shift of s_lshl_b64 exec), the quad
+//     address is one s_mul_i32 feeding the SGPR-offset form of s_load;
+//   * REGISTER HAND-OFF (round 3).  Every quad but the root used to be pushed once (three v_writelane) and popped
+//     once (three v_readfirstlane) although its entry sits in SGPRs when it is made.  Now the FIRST child of A
+//     that some lane opens stays in scalar registers and is the next iteration's A (NA: index s72, lane mask
+//     s[68:69], moved to s[44:45] when A's own mask dies); the first opened child of B becomes the next B (NB:
+//     index s70, mask s[68:69] -> s[46:47]).  Only the other opened children go through the VGPR stack.  Which
+//     child opens first is known at run time only, so each child block exists in two flavours -- "slot free"
+//     (BH_CHILD_F: the open mask is computed straight into the hand-off pair; a taken child costs one s_mov and
+//     leaves through BH_TAKE, which carries a copy of the force math and continues in the other chain) and "slot
+//     taken" (BH_CHILD_T: push) -- and the program counter remembers the state;
+//   * s_setprio 2 between an iteration's start and its s_waitcnt: the waves that are about to issue their loads go
+//     first, the others are evaluating (-1.3 %; priorities 1..3 measure the same).
+// Abstract machine (the C++ loop in the kernel implements the same one, bit for bit --
+// tests/test_gpu_fp32.py::test_asm_walk_equals_the_portable_walk):
+//   A := NA, else the stack's top (a bucket reference is served on the spot and the iteration ends), else NB, else done;
+//   B := NB, else -- if the stack is not empty and holds at most pair_limit entries -- its top (a bucket reference
+//        is left there), else none;            [two quads in flight per wave: one s_waitcnt serves both]
+//   evaluate A: the first opened child that is a quad becomes NA, other opened children are pushed;
+//   evaluate B: likewise with NB, but only if the stack holds at most pair_limit entries when B's evaluation starts.
+// Stack bound.  Entries live in six VGPRs addressed by lane: 128 entries.  An iteration with a B is entered with at
+// most pair_limit + 3 entries (an NB was taken at <= pair_limit entries and at most 3 pushes followed; a popped B
+// leaves <= pair_limit - 1) and pushes at most 8; from S entries a run of single-quad iterations (depth first:
+// three waiting siblings per level, four at the last) never holds more than S + 3 * Dm + 1; with pair_limit =
+// 116 - 3 * Dm (56 at max_depth 21, 23 at 32) the 128 entries always suffice -- the engine passes it in (0 = never
+// pair).  An iteration that starts with at most 56 entries touches only the first register triple and runs a
+// copy of the loop without the "which triple?" tests.
+// Hazards handled by instruction order (the assembler inserts no wait states into inline assembly): the consumer
+// of v_rsq_f32 is separated from it by the scalar push logic; the consumer of v_pk_add_f32 by the empty-cell test;
+// m0 is written at least one instruction before a lane select uses it.
+// Fixed SGPRs: s[24:43] quad A, s[44:45] its lane mask, s[46:47] B's mask (0: no B in flight), s[48:67] quad B,
+// s68 / s69 A's quad index and byte offset and, once the loads are issued, the hand-off pair (also the open-mask
+// scratch of the "free" flavour), s70 / s71 B's index and offset, then the open-mask scratch of the "taken" flavour
+// while A is evaluated (s[24:25] while B is: quad A is dead by then), s72 NA's index (-1: none), s70 NB's index
+// between iterations (-1: none).  The block sits right above the ~20 SGPRs the compiler keeps live across the
+// loop: 79 in all, and a wave's allocation is its count + 16 rounded up to 16 out of 800 per SIMD -- 80 is the
+// last value that leaves 8 resident waves (tests/test_kernel_resources_cpu.py).
+// Fixed VGPRs (the two-dword operands of v_pk_add_f32 need named halves): v[20:21] body position, v[22:23] dx,dy,
+// v24 d2 then w, v25 1/d, v26 scratch, v[28:29] acceleration sums, v30..v32 / v33..v35 the stack.
+// -DBH_ASM_GUARD=1 (first run of a rewritten loop on hardware): a wave leaves after 2^20 iterations whatever its
+// stack says.
 #if defined(BH_ASM_GUARD) && BH_ASM_GUARD
 #define BH_LOOP_GUARD "s_cmp_gt_u32 %[cost], 0x100000\n s_cbranch_scc1 Ldone_%=\n"
 #else
 #define BH_LOOP_GUARD ""
 #endif
-#if BH_X_ALIGN
-#define BH_LOOP_ALIGN ".p2align " BH_STR(BH_X_ALIGN) "\n"
-#else
-#define BH_LOOP_ALIGN ""
-#endif
-#if BH_ASM_PAD_SALU
-#define BH_PAD_S "s_mov_b32 s70, s70\n s_mov_b32 s70, s70\n s_mov_b32 s70, s70\n s_mov_b32 s70, s70\n"
-#else
-#define BH_PAD_S ""
-#endif
-// PUSHCHK: "" in an iteration that starts with at most 56 entries (two pops, at most eight pushes: every
-// entry it touches sits in lanes of v30..v32), BH_PUSHCHK(TAG) otherwise (entries 64..127 live in v33..v35)
-#define BH_CHILD(XY, MS, TS, CS, MASK, TAG, PUSHCHK, PF)                                                \
-    "v_pk_add_f32 v[22:23], " XY ", v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n"                           \
-    "s_cmp_eq_u32 " MS ", 0\n"                                                                      \
-    "s_cbranch_scc1 Lnext" TAG "_%=\n"                                                              \
-    "v_mul_f32_e32 v24, v23, v23\n"                                                                 \
-    "v_fmac_f32_e32 v24, v22, v22\n"                                                                \
-    "v_cmpx_lt_f32_e32 vcc, " TS ", v24\n"                                                          \
-    BH_FORCE_RSQ_EARLY                                                                              \
-    "s_andn2_b64 s[68:69], " MASK ", vcc\n"                                                         \
-    "s_cbranch_scc0 Lforce" TAG "_%=\n"                                                             \
-    "s_cmp_eq_u32 " CS ", -1\n"                                                                     \
-    "s_cbranch_scc1 Lforce" TAG "_%=\n"                                                             \
-    PUSHCHK                                                                                         \
-    "v_writelane_b32 v30, " CS ", m0\n"                                                             \
-    "v_writelane_b32 v31, s68, m0\n"                                                                \
-    "v_writelane_b32 v32, s69, m0\n"                                                                \
-    "LpushBack" TAG "_%=:\n"                                                                        \
-    "s_add_u32 m0, m0, 1\n"                                                                         \
-    PF                                                                                              \
-    "Lforce" TAG "_%=:\n"                                                                           \
-    BH_FORCE_HEAD(TAG)                                                                              \
-    "v_mul_f32_e32 v26, " MS ", v25\n"                                                              \
-    "v_mul_f32_e32 v26, v25, v26\n"                                                                 \
-    "v_mul_f32_e32 v24, v25, v26\n"                                                                 \
-    "v_fmac_f32_e32 v28, v24, v22\n"                                                                \
-    "v_fmac_f32_e32 v29, v24, v23\n"                                                                \
-    BH_PAD_V BH_PAD_S                                                                               \
-    BH_FORCE_TAIL(TAG)                                                                              \
-    "s_mov_b64 exec, " MASK "\n"                                                                    \
-    "Lnext" TAG "_%=:\n"
-// (the lane select of v_writelane and the shift count of s_lshl_b64 use m0[5:0]: entry k sits in lane k & 63)
-#define BH_PUSHCHK(TAG) "s_bitcmp1_b32 m0, 6\n s_cbranch_scc1 LpushHi" TAG "_%=\n"
-#define BH_PUSH_HI(CS, TAG)                                                                         \
-    "LpushHi" TAG "_%=:\n"                                                                          \
-    "v_writelane_b32 v33, " CS ", m0\n"                                                             \
-    "v_writelane_b32 v34, s68, m0\n"                                                                \
-    "v_writelane_b32 v35, s69, m0\n"                                                                \
-    "s_branch LpushBack" TAG "_%=\n"
-// pop: EXEC = the entry's lane, v_readfirstlane (4.1 cycles each; v_readlane: 8.3)
-#define BH_POP_FAST(IDX, LO, HI)                                                                    \
-    "s_lshl_b64 exec, 1, m0\n"                                                                      \
-    "v_readfirstlane_b32 " IDX ", v30\n v_readfirstlane_b32 " LO ", v31\n v_readfirstlane_b32 " HI ", v32\n"
-#define BH_POP(IDX, LO, HI, TAG)                                                                    \
-    "s_lshl_b64 exec, 1, m0\n"                                                                      \
-    "s_bitcmp1_b32 m0, 6\n"                                                                         \
-    "s_cbranch_scc1 LpopHi" TAG "_%=\n"                                                             \
-    "v_readfirstlane_b32 " IDX ", v30\n v_readfirstlane_b32 " LO ", v31\n v_readfirstlane_b32 " HI ", v32\n" \
-    "LpopBack" TAG "_%=:\n"
-#define BH_POP_HI(IDX, LO, HI, TAG)                                                                 \
-    "LpopHi" TAG "_%=:\n"                                                                           \
-    "v_readfirstlane_b32 " IDX ", v33\n v_readfirstlane_b32 " LO ", v34\n v_readfirstlane_b32 " HI ", v35\n" \
-    "s_branch LpopBack" TAG "_%=\n"
-// one iteration: entries A (and B), loads, evaluation.  SFX distinguishes the two copies' labels.
-#if BH_X_LOADA_FIRST
-#define BH_ITERATION(SFX, POPA, POPB, CHK)                                                          \
-    "s_sub_u32 m0, m0, 1\n"                              /* SCC = borrow: the stack was empty */    \
-    "s_cbranch_scc1 Ldone_%=\n"                                                                     \
-    BH_PRIO_HI                                                                                      \
-    POPA                                                                                            \
-    "s_cmp_lt_i32 s68, 0\n"                                                                         \
-    "s_cbranch_scc1 Lspecial_%=\n"                                                                  \
-    "LloadA" SFX "_%=:\n"                                /* s68 = quad index >= 0, s[44:45] = mask */ \
-    "s_mul_i32 s69, s68, 0x50\n"                                                                    \
-    "s_load_dwordx16 s[24:39], %[quads], s69\n"                                                     \
-    "s_load_dwordx4 s[40:43], %[quads], s69 offset:0x40\n"                                          \
-    "s_mov_b32 s71, 0\n"                                 /* s71 != 0: a second quad (B) is in flight */ \
-    "s_cmp_eq_u32 m0, 0\n"                                                                          \
-    "s_cbranch_scc1 LwaitA" SFX "_%=\n"                                                             \
-    "s_cmp_gt_u32 m0, %[plim]\n"                         /* pairs only while the stack bound allows */ \
-    "s_cbranch_scc1 LwaitA" SFX "_%=\n"                                                             \
-    "s_sub_u32 m0, m0, 1\n"                                                                         \
-    POPB                                                                                            \
-    "s_cmp_lt_i32 s70, 0\n"                                                                         \
-    "s_cbranch_scc1 Lunpop" SFX "_%=\n"                                                             \
-    "s_mul_i32 s71, s70, 0x50\n"                         /* (a quad index >= 1: the offset is not 0) */ \
-    "s_load_dwordx16 s[48:63], %[quads], s71\n"                                                     \
-    "s_load_dwordx4 s[64:67], %[quads], s71 offset:0x40\n"                                          \
-    "LwaitA" SFX "_%=:\n"                                                                           \
-    "s_mov_b64 exec, s[44:45]\n"                                                                    \
-    "s_waitcnt lgkmcnt(0)\n"                                                                        \
-    BH_PRIO_LO                                                                                      \
-    BH_CHILD("s[24:25]", "s32", "s36", "s40", "s[44:45]", SFX "A0", CHK(SFX "A0"), BH_PREFETCH("s40"))  \
-    BH_CHILD("s[26:27]", "s33", "s37", "s41", "s[44:45]", SFX "A1", CHK(SFX "A1"), BH_PREFETCH("s41"))  \
-    BH_CHILD("s[28:29]", "s34", "s38", "s42", "s[44:45]", SFX "A2", CHK(SFX "A2"), BH_PREFETCH("s42"))  \
-    BH_CHILD("s[30:31]", "s35", "s39", "s43", "s[44:45]", SFX "A3", CHK(SFX "A3"), BH_PREFETCH("s43"))  \
-    "s_cmp_eq_u32 s71, 0\n"                                                                         \
-    "s_cbranch_scc1 Lloop_%=\n"                                                                     \
-    "s_mov_b64 exec, s[46:47]\n"                                                                    \
-    BH_CHILD("s[48:49]", "s56", "s60", "s64", "s[46:47]", SFX "B0", CHK(SFX "B0"), BH_PREFETCH("s64"))  \
-    BH_CHILD("s[50:51]", "s57", "s61", "s65", "s[46:47]", SFX "B1", CHK(SFX "B1"), BH_PREFETCH("s65"))  \
-    BH_CHILD("s[52:53]", "s58", "s62", "s66", "s[46:47]", SFX "B2", CHK(SFX "B2"), BH_PREFETCH("s66"))  \
-    BH_CHILD("s[54:55]", "s59", "s63", "s67", "s[46:47]", SFX "B3", CHK(SFX "B3"), BH_PREFETCH("s67"))  \
-    "s_branch Lloop_%=\n"                                                                           \
-    "Lunpop" SFX "_%=:\n"                                /* B is a bucket reference: leave it there */ \
-    "s_add_u32 m0, m0, 1\n"                                                                         \
-    "s_branch LwaitA" SFX "_%=\n"
-#else
-#define BH_ITERATION(SFX, POPA, POPB, CHK)                                                          \
-    "s_sub_u32 m0, m0, 1\n"                              /* SCC = borrow: the stack was empty */    \
-    "s_cbranch_scc1 Ldone_%=\n"                                                                     \
-    BH_PRIO_HI                                                                                      \
-    POPA                                                                                            \
-    "s_cmp_lt_i32 s68, 0\n"                                                                         \
-    "s_cbranch_scc1 Lspecial_%=\n"                                                                  \
-    "s_mov_b32 s71, 0\n"                                 /* s71 != 0: a second quad (B) is in flight */ \
-    "s_cmp_eq_u32 m0, 0\n"                                                                          \
-    "s_cbranch_scc1 LloadA" SFX "_%=\n"                                                             \
-    "s_cmp_gt_u32 m0, %[plim]\n"                         /* pairs only while the stack bound allows */ \
-    "s_cbranch_scc1 LloadA" SFX "_%=\n"                                                             \
-    "s_sub_u32 m0, m0, 1\n"                                                                         \
-    POPB                                                                                            \
-    "s_cmp_lt_i32 s70, 0\n"                                                                         \
-    "s_cbranch_scc1 Lunpop" SFX "_%=\n"                                                             \
-    "s_mul_i32 s71, s70, 0x50\n"                         /* (a quad index >= 1: the offset is not 0) */ \
-    "s_load_dwordx16 s[48:63], %[quads], s71\n"                                                     \
-    "s_load_dwordx4 s[64:67], %[quads], s71 offset:0x40\n"                                          \
-    "LloadA" SFX "_%=:\n"                                /* s68 = quad index >= 0, s[44:45] = mask */ \
-    "s_mul_i32 s69, s68, 0x50\n"                                                                    \
-    "s_load_dwordx16 s[24:39], %[quads], s69\n"                                                     \
-    "s_load_dwordx4 s[40:43], %[quads], s69 offset:0x40\n"                                          \
-    "s_mov_b64 exec, s[44:45]\n"                                                                    \
-    "s_waitcnt lgkmcnt(0)\n"                                                                        \
-    BH_PRIO_LO                                                                                      \
-    BH_CHILD("s[24:25]", "s32", "s36", "s40", "s[44:45]", SFX "A0", CHK(SFX "A0"), BH_PREFETCH("s40"))                  \
-    BH_CHILD("s[26:27]", "s33", "s37", "s41", "s[44:45]", SFX "A1", CHK(SFX "A1"), BH_PREFETCH("s41"))                  \
-    BH_CHILD("s[28:29]", "s34", "s38", "s42", "s[44:45]", SFX "A2", CHK(SFX "A2"), BH_PREFETCH("s42"))                  \
-    BH_CHILD("s[30:31]", "s35", "s39", "s43", "s[44:45]", SFX "A3", CHK(SFX "A3"), BH_PREFETCH("s43"))                  \
-    "s_cmp_eq_u32 s71, 0\n"                                                                         \
-    "s_cbranch_scc1 Lloop_%=\n"                                                                     \
-    "s_mov_b64 exec, s[46:47]\n"                                                                    \
-    BH_CHILD("s[48:49]", "s56", "s60", "s64", "s[46:47]", SFX "B0", CHK(SFX "B0"), BH_PREFETCH("s64"))                  \
-    BH_CHILD("s[50:51]", "s57", "s61", "s65", "s[46:47]", SFX "B1", CHK(SFX "B1"), BH_PREFETCH("s65"))                  \
-    BH_CHILD("s[52:53]", "s58", "s62", "s66", "s[46:47]", SFX "B2", CHK(SFX "B2"), BH_PREFETCH("s66"))                  \
-    BH_CHILD("s[54:55]", "s59", "s63", "s67", "s[46:47]", SFX "B3", CHK(SFX "B3"), BH_PREFETCH("s67"))                  \
-    "s_branch Lloop_%=\n"                                                                           \
-    "Lunpop" SFX "_%=:\n"                                /* B is a bucket reference: leave it there */ \
-    "s_add_u32 m0, m0, 1\n"                                                                         \
-    "s_branch LloadA" SFX "_%=\n"
-#endif
-#define BH_NOCHK(TAG) ""
-
-// Traversal order (shared with the C++ loop below, bit for bit): the root quad alone; then, as long as
-// the stack holds entries: take the top entry A; a bucket reference is served on the spot; otherwise, if
-// another entry B lies below it (and the stack is not deeper than pair_limit, see below), take B as well, issue the
-// loads of BOTH quads, wait once, evaluate A, then B.  Two quads in flight per wave: a wave spends half
-// of its life waiting for a quad (the scalar data cache serves a record in 400-640 cycles under load
-// whatever its size or alignment, scripts/calib/sload_chase.hip), and with 4 instead of 8 resident waves
-// per SIMD the kernel takes 1.68 times as long -- it is latency- not issue-bound.
-// Stack bound.  Entries live in six VGPRs addressed by lane: 128 entries.  A depth-first phase that starts
-// from S entries never holds more than S + 3 * Dm + 1 (three waiting siblings per level below the entry
-// taken, four at the last); a pair iteration is entered with at most pair_limit + 1 entries and leaves at
-// most pair_limit + 7.  With pair_limit = 120 - 3 * Dm (60 at max_depth 21, 27 at max_depth 32) the stack
-// never exceeds 128 entries whatever the tree -- the engine passes it in (0 = never pair).
-// returns the number of loop iterations (the cost of this group's walk of this tree)
-// consts: device block {aux, sorted positions, sorted masses} -- three pointers only the bucket path needs,
-// kept out of the SGPR budget (the kernel must stay at or below 80 SGPRs for 8 resident waves per SIMD:
-// the allocation is the count + 16, rounded up to 16, out of 800 per SIMD)
-__device__ __forceinline__ uint32_t walk_tree_asm(const QuadF BH_CONSTANT *quads, const void BH_CONSTANT *consts,
-                                                  int32_t root, uint64_t everyone, int32_t pair_limit, float px,
-                                                  float py, float &ax, float &ay)
-{
-    uint32_t cost;
-    asm volatile(
-        "v_mov_b32_e32 v20, %[px]\n"
-        "v_mov_b32_e32 v21, %[py]\n"
-        "v_mov_b32_e32 v28, %[ax]\n"
-        "v_mov_b32_e32 v29, %[ay]\n"
-        "s_mov_b32 m0, 0\n"                                     // (s68 = root quad, s[44:45] = lane mask: bound operands)
-        "s_mov_b32 s71, 0\n"
-        "s_mov_b32 %[cost], 1\n"                                // loop iterations: the group's cost (re-balancing weight)
-        "s_branch LloadAF_%=\n"                                 // the root quad alone
-        // ---------------------------------------------------------------- next entries
-        BH_LOOP_ALIGN
-        "Lloop_%=:\n"
-        "s_add_u32 %[cost], %[cost], 1\n"
-        "s_cmp_gt_u32 m0, 56\n"
-        "s_cbranch_scc1 LloopChk_%=\n"
-        BH_ITERATION("F", BH_POP_FAST("s68", "s44", "s45"), BH_POP_FAST("s70", "s46", "s47"), BH_NOCHK)
-        "LloopChk_%=:\n"                                        // more than 56 entries: pushes / pops pick their VGPRs
-        BH_ITERATION("C", BH_POP("s68", "s44", "s45", "A"), BH_POP("s70", "s46", "s47", "B"), BH_PUSHCHK)
-        BH_PUSH_HI("s40", "CA0") BH_PUSH_HI("s41", "CA1") BH_PUSH_HI("s42", "CA2") BH_PUSH_HI("s43", "CA3")
-        BH_PUSH_HI("s64", "CB0") BH_PUSH_HI("s65", "CB1") BH_PUSH_HI("s66", "CB2") BH_PUSH_HI("s67", "CB3")
-        BH_POP_HI("s68", "s44", "s45", "A")
-        BH_POP_HI("s70", "s46", "s47", "B")
-        // ---- bucket reference -(node id) - 2: the cell's bodies one by one for the lanes that reached it
-        //      (self and exactly coincident bodies contribute nothing: d2 > 0 fails); -1 is dropped
-        "Lspecial_%=:\n"
-        "s_cmp_eq_u32 s68, -1\n"
-        "s_cbranch_scc1 Lloop_%=\n"
-        "s_load_dwordx8 s[56:63], %[consts], 0x0\n"              // {aux, sorted positions, sorted masses}: this path only
-        "s_sub_i32 s68, -2, s68\n"
-        "s_lshl_b32 s69, s68, 3\n"
-        "s_mov_b64 exec, s[44:45]\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_load_dwordx2 s[48:49], s[56:57], s69\n"              // {first sorted body, count}
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_cmp_lt_i32 s49, 1\n"
-        "s_cbranch_scc1 Lloop_%=\n"
-        "s_add_u32 s49, s48, s49\n"
-        "Lbody_%=:\n"
-        "s_lshl_b32 s69, s48, 3\n"
-        "s_load_dwordx2 s[50:51], s[58:59], s69\n"
-        "s_lshl_b32 s69, s48, 2\n"
-        "s_load_dword s52, s[60:61], s69\n"
-        "s_add_u32 s48, s48, 1\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_pk_add_f32 v[22:23], s[50:51], v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n"
-        "s_cmp_lt_u32 s48, s49\n"                         // loop condition (and the packed result's wait state)
-        "v_mul_f32_e32 v24, v23, v23\n"
-        "v_fmac_f32_e32 v24, v22, v22\n"
-        "v_cmpx_lt_f32_e32 vcc, 0, v24\n"
-        "v_rsq_f32_e32 v25, v24\n"
-        "s_nop 0\n"                                             // wait state between v_rsq and its use
-        "v_mul_f32_e32 v26, s52, v25\n"
-        "v_mul_f32_e32 v26, v25, v26\n"
-        "v_mul_f32_e32 v24, v25, v26\n"
-        "v_fmac_f32_e32 v28, v24, v22\n"
-        "v_fmac_f32_e32 v29, v24, v23\n"
-        "s_mov_b64 exec, s[44:45]\n"
-        "s_cbranch_scc1 Lbody_%=\n"
-        "s_branch Lloop_%=\n"
-        "Ldone_%=:\n"
-        "s_mov_b64 exec, -1\n"                                  // (the kernel runs the traversal with all lanes enabled)
-        "v_mov_b32_e32 %[ax], v28\n"
-        "v_mov_b32_e32 %[ay], v29\n"
-        : [ax] "+v"(ax), [ay] "+v"(ay), [cost] "=&s"(cost), "+{s68}"(root), "+{s[44:45]}"(everyone)
-        : [quads] "s"(quads), [consts] "s"(consts), [px] "v"(px), [py] "v"(py), [plim] "s"(pair_limit)
-        : "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39",
-          "s40", "s41", "s42", "s43", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
-          "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s69", "s70", "s71",
-#if BH_X_PREFETCH
-          "s72",
-#endif
-          "m0", "vcc", "scc", "memory",
-          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35");
-    return cost;
-}
-// ---- round 3: the same loop with a REGISTER HAND-OFF of the first opened child ---------------------------------
-// Every quad but the root used to be pushed once (three v_writelane, 12.6 cycles of vector issue) and popped once
-// (three v_readfirstlane, 12.3): 25 of the ~138 vector cycles a quad costs, for data that
-// already sit in SGPRs when the next iteration wants them.  Here the FIRST child of A that some lane opens stays
-// in scalar registers and becomes the next iteration's A (NA: index s72, lane mask s[68:69], moved to s[44:45]
-// when A's own mask dies); likewise the first opened child of B becomes the next B (NB: index s70, mask s[68:69]
-// -> s[46:47]).  Only the other opened children go through the VGPR stack.  Which child opens first is only
-// known at run time, so each child block exists in two flavours -- "slot free" (BH_CHILD_F: the open mask is
-// computed straight into the hand-off pair, a taken child costs one s_mov and leaves through BH_TAKE, which
-// carries a copy of the force math and continues in the other chain) and "slot taken" (BH_CHILD_T: the push of
-// the old loop) -- and the program counter remembers the state.
-// Abstract machine (the C++ loop below implements the same one, bit for bit):
-//   A := NA, else the stack's top (a bucket reference is served on the spot and the iteration ends), else NB, else done;
-//   B := NB, else -- if the stack is not empty and holds at most pair_limit entries -- its top (a bucket reference
-//        is left there), else none;
-//   evaluate A: the first opened child that is a quad becomes NA, other opened children are pushed;
-//   evaluate B: likewise with NB, but only if the stack holds at most pair_limit entries when B's evaluation starts.
-// Stack bound: an iteration with a B is entered with at most pair_limit + 3 entries (an NB was taken at
-// <= pair_limit entries and at most 3 pushes followed; a popped B leaves <= pair_limit - 1) and pushes at most 7;
-// from S entries a run of single-quad iterations (depth first: three waiting siblings per level, four at the
-// last) never holds more than S + 3 * Dm + 1; with pair_limit = 116 - 3 * Dm the 128 entries always suffice.
-// Fixed SGPRs as in walk_tree_asm, except: s[68:69] is the hand-off pair (and the open-mask scratch of the
-// "free" flavour), s[70:71] / s[24:25] the open-mask scratch of the "taken" flavour while A / B is evaluated
-// (B's index and offset, resp. quad A, are dead by then), s72 NA's index (-1: none), s70 NB's index between
-// iterations (-1: none), "no B in flight" is s[46:47] == 0.
 #define BH_FORCE_MATH(MS, MASK)                                                                     \
     "v_mul_f32_e32 v26, " MS ", v25\n"                                                              \
     "v_mul_f32_e32 v26, v25, v26\n"                                                                 \
@@ -452,6 +142,8 @@ __device__ __forceinline__ uint32_t walk_tree_asm(const QuadF BH_CONSTANT *quads
     "v_fmac_f32_e32 v28, v24, v22\n"                                                                \
     "v_fmac_f32_e32 v29, v24, v23\n"                                                                \
     "s_mov_b64 exec, " MASK "\n"
+// v_pk_add_f32 sits ABOVE the empty-cell test: the two scalar instructions of the test are the wait state a packed
+// result needs before it is read (an empty child wastes those 4 cycles)
 #define BH_CHILD_HEAD(XY, MS, TS, MASK, SPAIR, TAG)                                                 \
     "v_pk_add_f32 v[22:23], " XY ", v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n"                           \
     "s_cmp_eq_u32 " MS ", 0\n"                                                                      \
@@ -462,7 +154,9 @@ __device__ __forceinline__ uint32_t walk_tree_asm(const QuadF BH_CONSTANT *quads
     "v_rsq_f32_e32 v25, v24\n"                                                                      \
     "s_andn2_b64 " SPAIR ", " MASK ", vcc\n"                                                        \
     "s_cbranch_scc0 Lforce" TAG "_%=\n"
-// slot taken: opened children (quads and bucket references) are pushed
+// slot taken (and the level-synchronous list walk): opened children -- quads and bucket references -- are pushed.
+// PUSHCHK: "" where every entry touched sits in lanes of v30..v32, BH_PUSHCHK(TAG) otherwise (entries 64..127
+// live in v33..v35)
 #define BH_CHILD_T(XY, MS, TS, CS, MASK, SPAIR, SLO, SHI, TAG, PUSHCHK)                             \
     BH_CHILD_HEAD(XY, MS, TS, MASK, SPAIR, TAG)                                                     \
     "s_cmp_eq_u32 " CS ", -1\n"                                                                     \
@@ -498,13 +192,30 @@ __device__ __forceinline__ uint32_t walk_tree_asm(const QuadF BH_CONSTANT *quads
     "s_mov_b32 " NIDX ", " CS "\n"                                                                  \
     BH_FORCE_MATH(MS, MASK)                                                                         \
     "s_branch " NEXT "_%=\n"
-#define BH_PUSH_HI2(CS, SLO, SHI, TAG)                                                              \
+// (the lane select of v_writelane and the shift count of s_lshl_b64 use m0[5:0]: entry k sits in lane k & 63)
+#define BH_PUSHCHK(TAG) "s_bitcmp1_b32 m0, 6\n s_cbranch_scc1 LpushHi" TAG "_%=\n"
+#define BH_NOCHK(TAG) ""
+#define BH_PUSH_HI(CS, SLO, SHI, TAG)                                                               \
     "LpushHi" TAG "_%=:\n"                                                                          \
     "v_writelane_b32 v33, " CS ", m0\n"                                                             \
     "v_writelane_b32 v34, " SLO ", m0\n"                                                            \
     "v_writelane_b32 v35, " SHI ", m0\n"                                                            \
     "s_branch LpushBack" TAG "_%=\n"
-#define BH_ITER2(SFX, POPA, POPB, CHK)                                                              \
+// pop: EXEC = the entry's lane, v_readfirstlane (4.1 cycles each; v_readlane: 8.3)
+#define BH_POP_FAST(IDX, LO, HI)                                                                    \
+    "s_lshl_b64 exec, 1, m0\n"                                                                      \
+    "v_readfirstlane_b32 " IDX ", v30\n v_readfirstlane_b32 " LO ", v31\n v_readfirstlane_b32 " HI ", v32\n"
+#define BH_POP(IDX, LO, HI, TAG)                                                                    \
+    "s_lshl_b64 exec, 1, m0\n"                                                                      \
+    "s_bitcmp1_b32 m0, 6\n"                                                                         \
+    "s_cbranch_scc1 LpopHi" TAG "_%=\n"                                                             \
+    "v_readfirstlane_b32 " IDX ", v30\n v_readfirstlane_b32 " LO ", v31\n v_readfirstlane_b32 " HI ", v32\n" \
+    "LpopBack" TAG "_%=:\n"
+#define BH_POP_HI(IDX, LO, HI, TAG)                                                                 \
+    "LpopHi" TAG "_%=:\n"                                                                           \
+    "v_readfirstlane_b32 " IDX ", v33\n v_readfirstlane_b32 " LO ", v34\n v_readfirstlane_b32 " HI ", v35\n" \
+    "s_branch LpopBack" TAG "_%=\n"
+#define BH_ITERATION(SFX, POPA, POPB, CHK)                                                              \
     /* ---- A: the handed-over child, else the stack's top, else the handed-over B */               \
     "s_cmp_gt_i32 s72, -1\n"                                                                        \
     "s_cbranch_scc1 LAn" SFX "_%=\n"                                                                \
@@ -546,8 +257,8 @@ __device__ __forceinline__ uint32_t walk_tree_asm(const QuadF BH_CONSTANT *quads
     "s_load_dwordx4 s[64:67], %[quads], s71 offset:0x40\n"                                          \
     "LW" SFX "_%=:\n"                                                                               \
     "s_mov_b64 exec, s[44:45]\n"                                                                    \
-    "s_waitcnt lgkmcnt(0)\n"                                                                        \
-    BH_PRIO_LO                                                                                      \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                    \
+    "s_setprio 0\n"                                                                                 \
     /* ---- A's children, hand-off slot free */                                                     \
     BH_CHILD_F("s[24:25]", "s32", "s36", "s40", "s[44:45]", SFX "A0f", CHK(SFX "A0f"))              \
     BH_CHILD_F("s[26:27]", "s33", "s37", "s41", "s[44:45]", SFX "A1f", CHK(SFX "A1f"))              \
@@ -605,16 +316,16 @@ __device__ __forceinline__ uint32_t walk_tree_asm(const QuadF BH_CONSTANT *quads
     BH_TAKE("s58", "s66", "s[46:47]", "s70", SFX "B2f", "LB3t" SFX)                                 \
     BH_TAKE("s59", "s67", "s[46:47]", "s70", SFX "B3f", "LBet" SFX)
 #define BH_HI_STUBS(SFX)                                                                            \
-    BH_PUSH_HI2("s40", "s68", "s69", SFX "A0f") BH_PUSH_HI2("s41", "s68", "s69", SFX "A1f")          \
-    BH_PUSH_HI2("s42", "s68", "s69", SFX "A2f") BH_PUSH_HI2("s43", "s68", "s69", SFX "A3f")          \
-    BH_PUSH_HI2("s41", "s70", "s71", SFX "A1t") BH_PUSH_HI2("s42", "s70", "s71", SFX "A2t")          \
-    BH_PUSH_HI2("s43", "s70", "s71", SFX "A3t")                                                     \
-    BH_PUSH_HI2("s64", "s68", "s69", SFX "B0f") BH_PUSH_HI2("s65", "s68", "s69", SFX "B1f")          \
-    BH_PUSH_HI2("s66", "s68", "s69", SFX "B2f") BH_PUSH_HI2("s67", "s68", "s69", SFX "B3f")          \
-    BH_PUSH_HI2("s64", "s24", "s25", SFX "B0t") BH_PUSH_HI2("s65", "s24", "s25", SFX "B1t")          \
-    BH_PUSH_HI2("s66", "s24", "s25", SFX "B2t") BH_PUSH_HI2("s67", "s24", "s25", SFX "B3t")
+    BH_PUSH_HI("s40", "s68", "s69", SFX "A0f") BH_PUSH_HI("s41", "s68", "s69", SFX "A1f")          \
+    BH_PUSH_HI("s42", "s68", "s69", SFX "A2f") BH_PUSH_HI("s43", "s68", "s69", SFX "A3f")          \
+    BH_PUSH_HI("s41", "s70", "s71", SFX "A1t") BH_PUSH_HI("s42", "s70", "s71", SFX "A2t")          \
+    BH_PUSH_HI("s43", "s70", "s71", SFX "A3t")                                                     \
+    BH_PUSH_HI("s64", "s68", "s69", SFX "B0f") BH_PUSH_HI("s65", "s68", "s69", SFX "B1f")          \
+    BH_PUSH_HI("s66", "s68", "s69", SFX "B2f") BH_PUSH_HI("s67", "s68", "s69", SFX "B3f")          \
+    BH_PUSH_HI("s64", "s24", "s25", SFX "B0t") BH_PUSH_HI("s65", "s24", "s25", SFX "B1t")          \
+    BH_PUSH_HI("s66", "s24", "s25", SFX "B2t") BH_PUSH_HI("s67", "s24", "s25", SFX "B3t")
 
-__device__ __forceinline__ uint32_t walk_tree_asm2(const QuadF BH_CONSTANT *quads, const void BH_CONSTANT *consts,
+__device__ __forceinline__ uint32_t walk_tree_asm(const QuadF BH_CONSTANT *quads, const void BH_CONSTANT *consts,
                                                    int32_t root, uint64_t everyone, int32_t pair_limit, float px,
                                                    float py, float &ax, float &ay)
 {
@@ -630,16 +341,15 @@ __device__ __forceinline__ uint32_t walk_tree_asm2(const QuadF BH_CONSTANT *quad
         "s_mov_b32 %[cost], 1\n"                                // loop iterations: the group's cost (re-balancing weight)
         "s_branch LArF_%=\n"                                    // the root quad alone
         // ---------------------------------------------------------------- next entries
-        BH_LOOP_ALIGN
         "Lloop_%=:\n"
         "s_add_u32 %[cost], %[cost], 1\n"
         BH_LOOP_GUARD
-        BH_PRIO_HI
+        "s_setprio 2\n"
         "s_cmp_gt_u32 m0, 56\n"
         "s_cbranch_scc1 LloopChk_%=\n"
-        BH_ITER2("F", BH_POP_FAST("s68", "s44", "s45"), BH_POP_FAST("s70", "s46", "s47"), BH_NOCHK)
+        BH_ITERATION("F", BH_POP_FAST("s68", "s44", "s45"), BH_POP_FAST("s70", "s46", "s47"), BH_NOCHK)
         "LloopChk_%=:\n"                                        // more than 56 entries: pushes / pops pick their VGPRs
-        BH_ITER2("C", BH_POP("s68", "s44", "s45", "A"), BH_POP("s70", "s46", "s47", "B"), BH_PUSHCHK)
+        BH_ITERATION("C", BH_POP("s68", "s44", "s45", "A"), BH_POP("s70", "s46", "s47", "B"), BH_PUSHCHK)
         BH_HI_STUBS("C")
         BH_POP_HI("s68", "s44", "s45", "A")
         BH_POP_HI("s70", "s46", "s47", "B")
@@ -682,6 +392,7 @@ __device__ __forceinline__ uint32_t walk_tree_asm2(const QuadF BH_CONSTANT *quad
         "s_cbranch_scc1 Lbody_%=\n"
         "s_branch Lloop_%=\n"
         "Ldone_%=:\n"
+        "s_setprio 0\n"
         "s_mov_b64 exec, -1\n"                                  // (the kernel runs the traversal with all lanes enabled)
         "v_mov_b32_e32 %[ax], v28\n"
         "v_mov_b32_e32 %[ay], v29\n"
@@ -696,7 +407,7 @@ __device__ __forceinline__ uint32_t walk_tree_asm2(const QuadF BH_CONSTANT *quad
 }
 // The same child blocks driven by a LIST of entries instead of the stack: the level-synchronous walk of small
 // launches (SPLIT > 1) hands every wave a chunk of at most 16 frontier entries, lane j of (in_base, in_lo,
-// in_hi) holding entry j.  They are taken in order, two at a time like the stack entries of walk_tree_asm
+// in_hi) holding entry j.  They are taken in order, two at a time
 // (a bucket reference is served alone), and the children some lane opens are pushed to a fresh stack that
 // starts at entry 0: at most 64 pushes, all in the first register triple.  Returns the number of pushes; the
 // stack itself comes back in (out_base, out_lo, out_hi).  Same operations in the same order as the C++ loop
@@ -740,17 +451,17 @@ __device__ __forceinline__ int32_t walk_list_asm(const QuadF BH_CONSTANT *quads,
         "s_load_dwordx4 s[40:43], %[quads], s69 offset:0x40\n"
         "s_mov_b64 exec, s[44:45]\n"
         "s_waitcnt lgkmcnt(0)\n"
-        BH_CHILD("s[24:25]", "s32", "s36", "s40", "s[44:45]", "LA0", "", "")
-        BH_CHILD("s[26:27]", "s33", "s37", "s41", "s[44:45]", "LA1", "", "")
-        BH_CHILD("s[28:29]", "s34", "s38", "s42", "s[44:45]", "LA2", "", "")
-        BH_CHILD("s[30:31]", "s35", "s39", "s43", "s[44:45]", "LA3", "", "")
+        BH_CHILD_T("s[24:25]", "s32", "s36", "s40", "s[44:45]", "s[68:69]", "s68", "s69", "LA0", "")
+        BH_CHILD_T("s[26:27]", "s33", "s37", "s41", "s[44:45]", "s[68:69]", "s68", "s69", "LA1", "")
+        BH_CHILD_T("s[28:29]", "s34", "s38", "s42", "s[44:45]", "s[68:69]", "s68", "s69", "LA2", "")
+        BH_CHILD_T("s[30:31]", "s35", "s39", "s43", "s[44:45]", "s[68:69]", "s68", "s69", "LA3", "")
         "s_cmp_eq_u32 s71, 0\n"
         "s_cbranch_scc1 Lloop_%=\n"
         "s_mov_b64 exec, s[46:47]\n"
-        BH_CHILD("s[48:49]", "s56", "s60", "s64", "s[46:47]", "LB0", "", "")
-        BH_CHILD("s[50:51]", "s57", "s61", "s65", "s[46:47]", "LB1", "", "")
-        BH_CHILD("s[52:53]", "s58", "s62", "s66", "s[46:47]", "LB2", "", "")
-        BH_CHILD("s[54:55]", "s59", "s63", "s67", "s[46:47]", "LB3", "", "")
+        BH_CHILD_T("s[48:49]", "s56", "s60", "s64", "s[46:47]", "s[68:69]", "s68", "s69", "LB0", "")
+        BH_CHILD_T("s[50:51]", "s57", "s61", "s65", "s[46:47]", "s[68:69]", "s68", "s69", "LB1", "")
+        BH_CHILD_T("s[52:53]", "s58", "s62", "s66", "s[46:47]", "s[68:69]", "s68", "s69", "LB2", "")
+        BH_CHILD_T("s[54:55]", "s59", "s63", "s67", "s[46:47]", "s[68:69]", "s68", "s69", "LB3", "")
         "s_branch Lloop_%=\n"
         // ---- bucket reference -(node id) - 2 (see walk_tree_asm); -1 is dropped
         "Lspecial_%=:\n"
@@ -806,13 +517,10 @@ __device__ __forceinline__ int32_t walk_list_asm(const QuadF BH_CONSTANT *quads,
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35");
     return sp;
 }
-#undef BH_CHILD
+#undef BH_CHILD_T
+#undef BH_CHILD_F
 #undef BH_ITERATION
 
-#ifndef BH_WALK_HANDOFF
-#define BH_WALK_HANDOFF 1      // 0: the round-2 loop (every opened child goes through the VGPR stack), A/B
-#endif
-constexpr bool kHandoff = BH_WALK_HANDOFF != 0;
 constexpr int kLdsStackDepth = 128;   // 3*31+4 entries worst case
 constexpr int kSplitFrontier = 512;   // split walk: frontier entries per level kept in LDS (12 B each, x2)
 constexpr int kSplitRound = 16;       // split walk: quads per wave per round (4 pushes each fill the 64-lane stack)
@@ -823,11 +531,11 @@ constexpr int kSplitRound = 16;       // split walk: quads per wave per round (4
 // One wave per 64 bodies takes TWO stack entries per iteration where it can (see walk_tree_asm):
 // fp32 mode does not need the reference's visiting order, so taking an entry off the stack before the
 // quad above it has pushed its children is allowed.
-template <bool LDS_STACK, bool STATS, int MODE, int SPLIT, bool ASM = false>
+template <bool LDS_STACK, bool STATS, int SPLIT, bool ASM = false>
 __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_kernel(WalkFastArgs a)
 {
-    static_assert(SPLIT == 1 || (!LDS_STACK && MODE == 0), "the split walk uses the register-lane stack, loop 0");
-    static_assert(!ASM || (!LDS_STACK && !STATS && MODE == 0), "the assembly loops serve the default configuration");
+    static_assert(SPLIT == 1 || !LDS_STACK, "the split walk uses the register-lane stack");
+    static_assert(!ASM || (!LDS_STACK && !STATS), "the assembly loops serve the default configuration");
     __shared__ int32_t s_base[LDS_STACK ? kWavesPerBlock : 1][LDS_STACK ? kLdsStackDepth : 1];
     __shared__ uint64_t s_mask[LDS_STACK ? kWavesPerBlock : 1][LDS_STACK ? kLdsStackDepth : 1];
     // split walk: two frontiers (current / next level), the waves' push counts, the partial sums
@@ -840,18 +548,11 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
 #ifdef BHGPU_EXPERIMENTS
     const uint64_t dbg_t0 = a.timeline ? __builtin_amdgcn_s_memrealtime() : 0;     // 100 MHz wall clock
 #endif
-    // Workgroup -> group of bodies.  Measured and rejected (kept in -DBHGPU_EXPERIMENTS builds): an
-    // XCD-aware placement (workgroups are dealt round-robin over the 8 XCDs, each with its own 4 MiB L2;
-    // XCD x takes the x-th CONTIGUOUS eighth of the sorted order) was neutral in round 1 and in round 2
-    // (0.376 vs 0.379 ms); reversed and strided dispatch orders change nothing either (0.378 / 0.384) --
-    // the tail of the launch is not an ordering effect.
-#ifdef BHGPU_EXPERIMENTS
-    uint32_t lb = a.xcd_chunk ? (blockIdx.x & 7u) * a.xcd_chunk + (blockIdx.x >> 3) : blockIdx.x;
-    if (a.order_mode == 1) lb = a.nblocks - 1 - blockIdx.x;                       // reversed
-    else if (a.order_mode == 2) lb = (uint32_t)(((uint64_t)blockIdx.x * 1021u) % a.nblocks);   // strided (nblocks coprime with 1021)
-#else
+    // Workgroup -> group of bodies: dispatch order.  (Measured and rejected, rounds 1-3: an XCD-contiguous placement --
+    // XCD x takes the x-th contiguous eighth of the sorted order -- halves the L2 misses of the launch, 1.61 M -> 0.81 M,
+    // and changes nothing: the waves that wait less for memory wait for an issue slot instead; reversed, strided and
+    // heaviest-first orders: nothing either.  DESIGN.md section 4.)
     const uint32_t lb = blockIdx.x;
-#endif
     if (lb >= a.nblocks) return;
     const int lane = lane_id(), w = wave_id();
     // SPLIT > 1: every wave of the workgroup holds the SAME 64 bodies
@@ -875,7 +576,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
     int32_t v_base2 = 0, v_lo2 = 0, v_hi2 = 0;   // first (k < 64) or second triple: 128 entries (walk_tree_asm)
     int sp = 0;                                   // wave-uniform
 
-    // hand-off slot of the quad being evaluated (walk_tree_asm2): the first opened child that is a quad lands here
+    // hand-off slot of the quad being evaluated (walk_tree_asm): the first opened child that is a quad lands here
     // instead of on the stack; h_free == false: everything is pushed
     bool h_free = false;
     int32_t h_idx = -1;
@@ -1098,47 +799,6 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
             for (int k = 1; k < SPLIT; ++k) { ax += f_red[k][lane].x; ay += f_red[k][lane].y; }
         }
         valid = valid && (w == 0);
-    } else if (MODE == 1) {
-        int32_t baseA = 0, baseB = 0;
-        uint64_t maskA = __ballot(valid), maskB = 0;
-        QuadRegs A = load_quad(quads), B;                   // quad 0: the root in slot 0
-        for (;;) {
-            // ---- A in hand: start the loads of the next entry, then evaluate A
-            const bool preB = pop_quad(baseB, maskB);
-            if (preB) B = load_quad(quads + baseB);
-            eval_quad(A, maskA);
-            if (!preB) {
-                if (!pop_quad(baseB, maskB)) break;
-                B = load_quad(quads + baseB);
-            }
-            // ---- B in hand
-            const bool preA = pop_quad(baseA, maskA);
-            if (preA) A = load_quad(quads + baseA);
-            eval_quad(B, maskB);
-            if (!preA) {
-                if (!pop_quad(baseA, maskA)) break;
-                A = load_quad(quads + baseA);
-            }
-        }
-    } else if (MODE == 2) {
-        // two stack entries per iteration: four scalar loads in flight per wait
-        int32_t b0 = 0, b1 = 0;
-        uint64_t m0 = __ballot(valid), m1 = 0;
-        {
-            const QuadRegs q = load_quad(quads);
-            eval_quad(q, m0);
-        }
-        while (pop_quad(b0, m0)) {
-            const bool two = pop_quad(b1, m1);
-            const QuadRegs A = load_quad(quads + b0);
-            if (two) {
-                const QuadRegs B = load_quad(quads + b1);
-                eval_quad(A, m0);
-                eval_quad(B, m1);
-            } else {
-                eval_quad(A, m0);
-            }
-        }
     } else {
         // the local tree, then (distributed step) the locally-essential tree of every peer: one
         // traversal per tree, so the stack never holds more than one tree's entries
@@ -1148,12 +808,11 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
             if (t >= 0 && t == a.self_rank) continue;
             int32_t base = (t < 0) ? 0 : (int32_t)(a.forest_base + (int64_t)t * a.let_cap);
             if (ASM) {
-                cost += kHandoff ? walk_tree_asm2(quads, as_constant(a.bucket_consts), base, everyone, a.pair_limit, p.x, p.y, ax, ay)
-                                 : walk_tree_asm(quads, as_constant(a.bucket_consts), base, everyone, a.pair_limit, p.x, p.y, ax, ay);
+                cost += walk_tree_asm(quads, as_constant(a.bucket_consts), base, everyone, a.pair_limit, p.x, p.y, ax, ay);
                 continue;
             }
-            if (kHandoff) {
-                // the C++ statement of walk_tree_asm2's abstract machine: same order, same operations
+            {
+                // the C++ statement of walk_tree_asm's abstract machine: same order, same operations
                 int32_t na = -1, nb = -1;                       // handed-over children (quad index, -1: none) ...
                 uint64_t nam = 0, nbm = 0;                      // ... and the lanes that opened them
                 bool first = true;
@@ -1190,37 +849,6 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
                         nb = h_idx; nbm = h_mask;
                     }
                     h_free = false;
-                }
-                continue;
-            }
-            // the C++ statement of walk_tree_asm's loop: same order, same operations
-            {
-                const QuadRegs q = load_quad(quads + base);
-                eval_quad(q, everyone);
-                ++cost;
-            }
-            while (sp > 0) {
-                ++cost;
-                int32_t bA, bB = 0;
-                uint64_t mA, mB = 0;
-                pop_raw(bA, mA);
-                if (bA < 0) {
-                    if (bA <= -2) bucket(-bA - 2, mA);          // -1 (a leaf opened by a NaN) is dropped
-                    continue;
-                }
-                bool two = false;
-                if (sp > 0 && sp <= a.pair_limit) {
-                    pop_raw(bB, mB);
-                    if (bB < 0) ++sp;                           // a bucket reference: leave it on the stack
-                    else two = true;
-                }
-                const QuadRegs A = load_quad(quads + bA);
-                if (two) {
-                    const QuadRegs B = load_quad(quads + bB);
-                    eval_quad(A, mA);
-                    eval_quad(B, mB);
-                } else {
-                    eval_quad(A, mA);
                 }
             }
         }
@@ -1306,63 +934,41 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
     }
 }
 
-template <bool L, bool S, int M, int SPLIT = 1, bool ASM = false>
-static hipError_t launch(WalkFastArgs a, bool xcd, hipStream_t st)
+template <bool L, bool S, int SPLIT = 1, bool ASM = false>
+static hipError_t launch(WalkFastArgs a, hipStream_t st)
 {
     const int64_t cnt = a.hi - a.lo;
     if (cnt <= 0) return hipSuccess;
     constexpr int per_group = SPLIT > 1 ? kWave : kBlock;
     a.nblocks = (uint32_t)((cnt + per_group - 1) / per_group);
-    a.xcd_chunk = xcd ? (a.nblocks + 7) / 8 : 0;
-    const unsigned grid = xcd ? 8 * a.xcd_chunk : a.nblocks;
-    unsigned lds_pad = 0;
-#ifdef BHGPU_EXPERIMENTS
-    // occupancy experiment: reserving LDS per workgroup lowers the number of resident waves per SIMD
-    // (40 KB -> 4 workgroups per CU = 4 waves per SIMD; 80 KB -> 2)
-    if (const char *e = std::getenv("BH_WALK_LDS_PAD")) lds_pad = (unsigned)std::atoi(e);
-#endif
-    hipLaunchKernelGGL((walk_fast_kernel<L, S, M, SPLIT, ASM>), dim3(grid), dim3(SPLIT > 1 ? kWave * SPLIT : kBlock), lds_pad, st, a);
+    hipLaunchKernelGGL((walk_fast_kernel<L, S, SPLIT, ASM>), dim3(a.nblocks), dim3(SPLIT > 1 ? kWave * SPLIT : kBlock), 0, st, a);
     return hipGetLastError();
 }
 
-template <bool L, bool S>
-static hipError_t launch_mode(const WalkFastArgs &a, int mode, bool xcd, hipStream_t st)
-{
-#ifdef BHGPU_EXPERIMENTS
-    switch (mode) {                     // the software-pipelined loops of round 1 (slower)
-    case 1: return launch<L, S, 1>(a, xcd, st);
-    case 2: return launch<L, S, 2>(a, xcd, st);
-    default: break;
-    }
-#endif
-    return launch<L, S, 0>(a, xcd, st);
-}
-
 template <bool S, bool ASM = false>
-static hipError_t launch_split(const WalkFastArgs &a, int split, bool xcd, hipStream_t st)
+static hipError_t launch_split(const WalkFastArgs &a, int split, hipStream_t st)
 {
     // (16 waves per group was instantiated through round 2: never the measured best at any size, and its
     // code object spilled 15 SGPRs into VGPR lanes around the assembly blocks; requests above 8 get 8)
     switch (split) {
-    case 2: return launch<false, S, 0, 2, ASM>(a, xcd, st);
-    case 4: return launch<false, S, 0, 4, ASM>(a, xcd, st);
-    default: return launch<false, S, 0, 8, ASM>(a, xcd, st);
+    case 2: return launch<false, S, 2, ASM>(a, st);
+    case 4: return launch<false, S, 4, ASM>(a, st);
+    default: return launch<false, S, 8, ASM>(a, st);
     }
 }
 
-hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, int mode, bool xcd, int split,
-                            bool use_asm, hipStream_t st)
+hipError_t launch_walk_fast(const WalkFastArgs &a, bool lds_stack, bool stats, int split, bool use_asm, hipStream_t st)
 {
     // the hand-scheduled loop serves the default configuration: one wave per 64 bodies, register-lane
     // stack, no counters; every other variant runs the C++ loops (same operations, same order)
-    if (use_asm && !lds_stack && !stats && mode == 0 && !walk_fast_split_effective(a, lds_stack, mode, split))
-        return launch<false, false, 0, 1, true>(a, xcd, st);
-    // the split walk exists for the register-lane stack and loop 0 only; its queue holds 56 roots
-    if (split > 1 && !lds_stack && mode == 0 && a.n_trees <= 56)
-        return stats ? launch_split<true>(a, split, xcd, st)
-                     : (use_asm ? launch_split<false, true>(a, split, xcd, st) : launch_split<false>(a, split, xcd, st));
-    if (lds_stack) return stats ? launch_mode<true, true>(a, mode, xcd, st) : launch_mode<true, false>(a, mode, xcd, st);
-    return stats ? launch_mode<false, true>(a, mode, xcd, st) : launch_mode<false, false>(a, mode, xcd, st);
+    if (use_asm && !lds_stack && !stats && !walk_fast_split_effective(a, lds_stack, split))
+        return launch<false, false, 1, true>(a, st);
+    // the split walk exists for the register-lane stack only; its queue holds 56 roots
+    if (walk_fast_split_effective(a, lds_stack, split))
+        return stats ? launch_split<true>(a, split, st)
+                     : (use_asm ? launch_split<false, true>(a, split, st) : launch_split<false>(a, split, st));
+    if (lds_stack) return stats ? launch<true, true>(a, st) : launch<true, false>(a, st);
+    return stats ? launch<false, true>(a, st) : launch<false, false>(a, st);
 }
 
 }  // namespace bh

@@ -379,6 +379,9 @@ class LetStepper:
             dist.all_reduce(fb, op=dist.ReduceOp.MAX)
         self.forest_base = int(fb.item())
         self._configure(let_cap)
+        # profile = True: step() brackets its phases with events on the current stream (phase_ms() reads them)
+        self.profile = False
+        self._marks = []
 
     def _configure(self, let_cap: int) -> None:
         self.let_cap = let_cap
@@ -411,9 +414,38 @@ class LetStepper:
             assert self.world == 1
             self.all_bounds.copy_(self.lbounds)
 
+    def _mark(self, marks) -> None:
+        if marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(ev)
+
+    def phase_ms(self) -> dict:
+        """Mean milliseconds per phase over the profiled steps since the last call (profile = True): bounds +
+        all_gather, local build + LET extraction, all_to_all, walk -- or, with overlap, the local walk under the
+        all_to_all, the part of the all_to_all that stayed exposed, and the remote walk.  Synchronises."""
+        torch.cuda.synchronize()
+        names = (["bounds_allgather", "build_let", "walk_local", "all_to_all_exposed", "walk_remote"] if self.overlap
+                 else ["bounds_allgather", "build_let", "all_to_all", "walk"])
+        acc = {k: 0.0 for k in names}
+        steps = [m for m in self._marks if len(m) == len(names) + 1]
+        for m in steps:
+            for k, (a, b) in zip(names, zip(m[:-1], m[1:])):
+                acc[k] += a.elapsed_time(b)
+        self._marks = []
+        out = {k: v / max(len(steps), 1) for k, v in acc.items()}
+        out["steps_profiled"] = len(steps)
+        return out
+
     def step(self, integrate: bool = True) -> None:
+        marks = [] if (self.profile and self.lbounds.is_cuda) else None
+        if marks is not None:
+            self._marks.append(marks)
+        self._mark(marks)
         self._exchange_bounds()
+        self._mark(marks)
         self.eng.let_build()
+        self._mark(marks)
         if dist.is_initialized() and self._staged():
             self.eng.sync()
             out = torch.empty(self.recv.numel(), dtype=self.recv.dtype)
@@ -421,22 +453,37 @@ class LetStepper:
             self.recv.copy_(out)
             if self.overlap:                                  # (nothing to overlap with here; same two launches)
                 self.eng.let_walk_local()
+                self._mark(marks)
+                self._mark(marks)
                 self.eng.let_walk_remote(integrate)
+                self._mark(marks)
                 return
         elif dist.is_initialized() and self.overlap:
             # block q of send -> block rank of q's recv, on the collective's own stream; the local-tree
             # walk does not need it, the second walk launch waits for it
             work = dist.all_to_all_single(self.recv, self.send, async_op=True)
             self.eng.let_walk_local()
+            self._mark(marks)
             work.wait()
+            self._mark(marks)
             self.eng.let_walk_remote(integrate)
+            self._mark(marks)
             return
         elif dist.is_initialized():
             dist.all_to_all_single(self.recv, self.send)
+        if self.overlap:                                      # (no process group: world 1)
+            self.eng.let_walk_local()
+            self._mark(marks)
+            self._mark(marks)
+            self.eng.let_walk_remote(integrate)
+            self._mark(marks)
+            return
+        self._mark(marks)
         if integrate:
             self.eng.let_walk()
         else:
             self.eng.let_forces()
+        self._mark(marks)
 
     @property
     def ids(self):

@@ -28,6 +28,7 @@ class Precision(enum.IntEnum):
     F64_EXACT = 0   # bit-identical to the reference CPU path
     F32 = 1         # throughput mode (BASELINE configs "fp32")
     MIXED = 2       # fp64 state, fp32 forces (BASELINE config "fp64 positions / fp32 forces")
+    F64 = 3         # fp64 throughout at throughput: the exact mode's tree, a free-order rsqrt walk (<= 1e-12 of the oracle)
 
 
 class BhError(RuntimeError):
@@ -72,6 +73,8 @@ class BhStats:
     walk_bytes: int = 0
     wave_quads: int = 0         # FLAG_WALK_STATS: quads loaded, once per wavefront
     sort_spill_buckets: int = 0  # bucket-sort buckets sorted through memory since creation (0 in steady motion)
+    let_tree_ms: float = 0.0    # last let_build: global box + local tree
+    let_pack_ms: float = 0.0    # last let_build: LET marking / numbering / packing
 
 
 def _dptr(a: np.ndarray):
@@ -198,7 +201,22 @@ class BarnesHutEngine:
         self._check(self._lib.bh_stats(self._h, C.byref(s)))
         return BhStats(s.n_bodies, s.n_nodes, s.n_internal, s.steps_done, s.visits, s.interactions,
                        s.wave_nodes, s.last_step_ms, s.build_ms, s.walk_ms, s.device_bytes, s.keys_ms, s.sort_ms,
-                       s.scan_ms, s.nodes_ms, s.build_bytes, s.walk_bytes, s.wave_quads, s.sort_spill_buckets)
+                       s.scan_ms, s.nodes_ms, s.build_bytes, s.walk_bytes, s.wave_quads, s.sort_spill_buckets,
+                       s.let_tree_ms, s.let_pack_ms)
+
+    def step_times(self):
+        """(step_ms[k], walk_ms[k]) of the steps of the last step() call (at most 4,096): HIP events per step."""
+        n = C.c_int32(0)
+        self._check(self._lib.bh_step_times(self._h, None, None, 0, C.byref(n)))
+        st, wk = np.zeros(max(n.value, 1)), np.zeros(max(n.value, 1))
+        self._check(self._lib.bh_step_times(self._h, _dptr(st), _dptr(wk), n.value, C.byref(n)))
+        return st[:n.value], wk[:n.value]
+
+    @staticmethod
+    def build_info() -> str:
+        """What the loaded library was built from (bh_build_info) and whether it is the product library."""
+        info = (_lib.load().bh_build_info() or b"").decode()
+        return info + ("" if _lib.is_product_library() else f" VARIANT={os.path.basename(_lib.LIB_PATH)}")
 
     # -- multi-GPU plumbing -----------------------------------------------------------------
     def set_owned_fraction(self, rank: int, world: int) -> None:

@@ -28,7 +28,8 @@ extern "C" {
 #endif
 
 #define BHGPU_ABI_VERSION 3   /* 2: bh_stats_t carries per-kernel-group times and algorithmic bytes;
-                                 3: bh_get_interaction_counts, bh_build_info */
+                                 3: bh_get_interaction_counts, bh_build_info, bh_step_times,
+                                    bh_stats_t.let_*_ms */
 
 typedef enum bh_status {
     BH_OK = 0,
@@ -51,7 +52,14 @@ typedef enum bh_precision {
      * are computed from the fp64 positions, the theta-walk runs in fp32 on rounded copies exactly
      * as in BH_PRECISION_F32.  For runs where a step's displacement is below the fp32 resolution
      * of the coordinates.  Single-GPU step and the LET distributed step; not the replicated one. */
-    BH_PRECISION_MIXED = 2
+    BH_PRECISION_MIXED = 2,
+    /* fp64 end to end like the reference (project.cu:38-65) at THROUGHPUT: the tree is the exact mode's, node
+     * for node bitwise the reference's; the walk takes the fp32 kernel's design (four sibling nodes per scalar
+     * load, free visiting order, 1/d by v_rsq_f64 + Newton steps instead of sqrt and three divisions).  Forces agree
+     * with the reference CPU path to summation rounding (<= 1e-12 relative, same per-body interaction counts), not
+     * bit for bit; trajectories therefore diverge from it as fast as the dynamics amplify 1e-15.  reference_compat,
+     * max_depth and the empty-node cut-off mean what they mean in BH_PRECISION_F64_EXACT.  Single GPU. */
+    BH_PRECISION_F64 = 3
 } bh_precision;
 
 /* bh_config.flags */
@@ -133,6 +141,9 @@ typedef struct bh_stats_t {
                                     wavefront (the walk's memory round trips)                 */
     uint64_t sort_spill_buckets; /* buckets of the bucket sort that did not fit on chip and were sorted
                                     through memory, since bh_create (0 in steady motion)      */
+    /* the last bh_let_build (distributed step), HIP events on the context's stream (ABI 3)  */
+    double   let_tree_ms;        /* global box + the local tree under it                     */
+    double   let_pack_ms;        /* marking, numbering and packing the peers' LETs           */
 } bh_stats_t;
 
 typedef struct bh_ctx bh_ctx;
@@ -192,7 +203,7 @@ int bh_get_accel(bh_ctx *ctx, double *accel);
 /* Per-body count of accepted force evaluations of the last walk -- the reference's walk has no such output; it is
  * the `inter++`-per-body of computeForces (project.cu:651-658 executed once per accepted node), which the parity
  * tests compare with the oracle's body by body: equal counts = the same acceptance decisions (project.cu:643).
- * Needs BH_FLAG_WALK_STATS; fp32 and mixed precision; caller order. */
+ * Needs BH_FLAG_WALK_STATS; fp32, mixed precision and BH_PRECISION_F64; caller order. */
 int bh_get_interaction_counts(bh_ctx *ctx, uint32_t *counts);
 
 /* --- tree output ------------------------------------------------------------------------
@@ -209,6 +220,11 @@ int bh_write_quadtree_file(bh_ctx *ctx, const char *path);
 
 /* --- measurement (replaces the std::chrono timers of project.cu:985-1007) ----------------*/
 int bh_stats(bh_ctx *ctx, bh_stats_t *out);
+/* Per step of the last bh_step call (at most 4,096 of them): step_ms[s] = end of step s-1's walk (or the start of
+ * the call) to the end of step s's walk, walk_ms[s] = that step's walk + integrate kernel -- HIP events on the
+ * context's stream.  The reference accumulates one total per run (project.cu:985-1007); a spread needs the steps.
+ * *n_out receives the number of steps available even when cap is too small; step_ms / walk_ms may be NULL. */
+int bh_step_times(bh_ctx *ctx, double *step_ms, double *walk_ms, int32_t cap, int32_t *n_out);
 
 /* --- multi-GPU plumbing -----------------------------------------------------------------
  * The reference is single-GPU.  One process per GPU owns a contiguous range [lo, hi) of

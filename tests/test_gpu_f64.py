@@ -1,0 +1,130 @@
+"""GPU parity, BH_PRECISION_F64 (the reference's arithmetic type at throughput, csrc/bh_walk_f64.hpp).
+
+The tree is the exact mode's -- checked bitwise against the reference's golden tree -- and the walk may visit nodes
+in another order and takes 1/d from v_rsq_f64 + Newton steps, so the stated tolerance is on the FORCES:
+    per body |F_gpu - F_ref| <= 1e-12 * |F_ref|      (reference = golden forces of project.cu's CPU path / the oracle)
+    per body: the same number of accepted force evaluations as the oracle (the same acceptance decisions)
+and on short trajectories <= 1e-11 x box width (the integration is the reference's kick-drift in fp64; the
+reference's dynamics amplify a 1e-15 difference by the step, so long runs are compared statistically only)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bh_oracle as O  # noqa: E402
+import gpu_nbody_simulation_amd as G  # noqa: E402
+from gpu_nbody_simulation_amd import initial_conditions as IC  # noqa: E402
+from gpu_nbody_simulation_amd.engine import FLAG_WALK_STATS  # noqa: E402
+
+TOL = 1e-12
+
+
+def rel(f, ref):
+    return np.linalg.norm(f - ref, axis=1) / np.linalg.norm(ref, axis=1)
+
+
+def engine(n, **kw):
+    kw.setdefault("precision", G.Precision.F64)
+    return G.BarnesHutEngine(G.BhConfig(capacity=n, **kw))
+
+
+def test_reference_forces_1024_and_the_reference_tree(gold, init1024):
+    """BASELINE config[0]'s bodies, the reference's depth cap and self skip: the tree bitwise the golden tree, the
+    forces within 1e-12 of the reference's own (golden), the walk's counters the oracle's."""
+    m, p, v = init1024
+    g = gold("ref_project_1024")
+    with engine(1024, flags=FLAG_WALK_STATS) as e:
+        e.upload(p, v, m)
+        f = e.compute_forces()
+        st = e.stats()
+        nodes, depth = e.export_tree()
+        cnt = e.interaction_counts()
+    rn, rd = O.canonical_tree(g["tree_0"])
+    assert np.array_equal(depth, rd)
+    for fld in ("comx", "comy", "mass", "xmin", "xmax", "ymin", "ymax", "particle"):
+        assert np.array_equal(nodes[fld], rn[fld]), fld
+    assert rel(f, g["forces_0"]).max() <= TOL
+    assert (st.visits, st.interactions) == (150509, 104117)                     # the oracle's counts (test_gpu_exact.py)
+    d = O.compute_forces_diag(O.build_tree(p, m, 10), p, m, compat_self_skip=True)
+    assert np.array_equal(cnt, d.counts)
+
+
+@pytest.mark.parametrize("name,md,compat", [("ref_project_40960", 10, True), ("ref_project_40960", 32, False),
+                                            ("ref_project_4096_grid", 10, True)])
+def test_forces_against_the_oracle_body_by_body(gold, name, md, compat):
+    g = gold(name)
+    m, p, v = g["mass"], g["pos"], g["vel"]
+    n = len(m)
+    with engine(n, max_depth=md, reference_compat=compat, flags=FLAG_WALK_STATS) as e:
+        e.upload(p, v, m)
+        f = e.compute_forces()
+        cnt = e.interaction_counts()
+    d = O.compute_forces_diag(O.build_tree(p, m, md if md < 32 else 0), p, m, compat_self_skip=compat)
+    ok = np.isfinite(d.forces).all(axis=1)                                     # (exactly coincident bodies: NaN in the reference)
+    assert ok.mean() > 0.999
+    assert rel(f[ok], d.forces[ok]).max() <= TOL
+    assert np.array_equal(cnt[ok], d.counts[ok])
+
+
+@pytest.mark.parametrize("kind,n,theta", [("plummer", 65536, 0.5), ("uniform", 65536, 0.3), ("uniform", 257, 0.5),
+                                          ("uniform", 2, 0.5), ("uniform", 1, 0.5)])
+def test_synthetic_distributions_against_the_uncapped_oracle(kind, n, theta):
+    m, p, v = IC.make(kind, n, 5, quasi_static=True)
+    with engine(n, max_depth=32, theta=theta, reference_compat=False, flags=FLAG_WALK_STATS) as e:
+        e.upload(p, v, m)
+        f = e.compute_forces()
+        cnt = e.interaction_counts()
+    d = O.compute_forces_diag(O.build_tree(p, m, 0), p, m, theta=theta, compat_self_skip=False)
+    if n == 1:
+        assert np.array_equal(f, np.zeros((1, 2))) and cnt[0] == 0
+        return
+    assert rel(f, d.forces).max() <= TOL
+    assert np.array_equal(cnt, d.counts)
+
+
+def test_agrees_with_the_bit_exact_mode_and_is_deterministic(gold):
+    """Same tree, same node values: the two fp64 walks differ by the order of a body's sum and the rsqrt only."""
+    g = gold("ref_project_40960")
+    m, p, v = g["mass"], g["pos"], g["vel"]
+    out = []
+    for prec in (G.Precision.F64_EXACT, G.Precision.F64, G.Precision.F64):
+        with engine(40960, precision=prec) as e:
+            e.upload(p, v, m)
+            out.append(e.compute_forces())
+    assert np.array_equal(out[0], g["forces_0"])                                # (the anchor is the golden one)
+    assert rel(out[1], out[0]).max() <= TOL
+    assert np.array_equal(out[1], out[2])
+
+
+def test_short_trajectory_on_the_encounter_free_fixture(gold):
+    g = gold("ref_project_4096_grid")
+    m, p, v = g["mass"], g["pos"], g["vel"]
+    po, vo = O.run(p, v, m, 10, max_depth=10)
+    with engine(4096) as e:
+        e.upload(p, v, m)
+        e.step(10)
+        pg, vg = e.download()
+    box = np.ptp(p, axis=0).max()
+    assert np.abs(pg - po).max() <= 1e-11 * box
+    assert np.abs(vg - vo).max() <= 1e-11 * np.abs(vo).max()
+
+
+def test_full_size_slice_and_properties():
+    """BASELINE config 3's size: N = 1,048,576 Plummer, theta 0.5, uncapped (max_depth 21 like the fp32 headline)."""
+    n = 1 << 20
+    m, p, v = IC.make("plummer", n, 1, quasi_static=True)
+    with engine(n, max_depth=21, reference_compat=True, flags=FLAG_WALK_STATS) as e:
+        e.upload(p, v, m)
+        f = e.compute_forces()
+        cnt = e.interaction_counts()
+        st = e.stats()
+        e.step(2)
+        pp, _ = e.download()
+    assert np.isfinite(pp).all()
+    t = O.build_tree(p, m, 21)
+    assert st.n_nodes == len(t)
+    lo, hi = 400000, 465536
+    d = O.compute_forces_diag(t, p, m, compat_self_skip=True, lo=lo, hi=hi)
+    ok = np.isfinite(d.forces[lo:hi]).all(axis=1)
+    assert rel(f[lo:hi][ok], d.forces[lo:hi][ok]).max() <= TOL
+    assert np.array_equal(cnt[lo:hi][ok], d.counts[lo:hi][ok])

@@ -93,6 +93,18 @@ def test_bench_exchange_path_on_real_rccl_single_rank(tmp_path):
         d = json.loads(line)
         assert d["n_gpus"] == 1 and d["value"] > 1e6 and 1 + 4 * 40000 < d["n_nodes"] < 4 * 65536
         assert 150 < d["interactions_per_body"] < 400
+        # the line explains itself on a multi-GPU node: what RCCL reported, which library ran, per-phase times
+        assert d["rccl"] == {"world_size": 1, "backend": "nccl"} and d["library"]["product"] is True
+        assert d["library"]["build_info"].startswith("digest=" + d["library"]["source_digest"])
+        if decomposition == "let":
+            ph = d["phases"]
+            names = ({"bounds_allgather", "build_let", "walk_local", "all_to_all_exposed", "walk_remote"} if extra
+                     else {"bounds_allgather", "build_let", "all_to_all", "walk"})
+            assert ph["steps_profiled"] == 3 and names <= set(ph["max_over_ranks"])
+            assert all(ph["max_over_ranks"][k] >= 0 for k in names) and ph["max_over_ranks"]["build_let"] > 0
+            assert ph["max_over_ranks"]["let_tree_last_step"] > 0 and ph["max_over_ranks"]["let_pack_last_step"] > 0
+            chk = d["let"]["direct_sum_check"]            # the forest against a distributed fp64 direct sum
+            assert chk["worst_rank_median_rel_err"] < 1e-2 and chk["max_rel_err"] < 0.2
 
 
 def test_bench_let_path_with_three_ranks_sharing_the_gpu(tmp_path):
@@ -123,6 +135,10 @@ def test_bench_let_path_with_three_ranks_sharing_the_gpu(tmp_path):
     # law to the multipole error (a broken exchange would leave O(1)), the shares are balanced, and the work
     # per body is that of the same state walked as ONE rank's forest (world size 1 through the same path).
     assert d["let"]["net_force_over_sum_abs_force"] < 2e-3
+    # ... and the forces every rank computed from the others' trees agree with a DISTRIBUTED fp64 direct sum
+    # (a stale, zero or mis-routed LET would be off by O(1); Newton's third law alone would not notice)
+    assert d["let"]["direct_sum_check"]["worst_rank_median_rel_err"] < 1e-2 and d["let"]["direct_sum_check"]["max_rel_err"] < 0.2
+    assert d["rccl"] == {"world_size": 3, "backend": "gloo"} and d["phases"]["steps_profiled"] == 3
     assert abs(d["let"]["bodies_on_rank0"] - 65536 / 3) < 0.15 * 65536 / 3
     r0 = subprocess.run([sys.executable] + base + ["--force-sharded"], capture_output=True, text=True, timeout=600, env=env)
     assert r0.returncode == 0, r0.stderr[-2000:]
