@@ -11,7 +11,7 @@
 //     register-lane stack (entry k in lane k of three VGPRs, 128 entries: depth-first needs <= 3 * max_depth + 1).
 //     A body's terms are therefore added in another order than the reference's: results agree with the oracle
 //     to summation rounding (tests: <= 1e-12 relative), not bit for bit.
-//   * 1/d by v_rsq_f64 and two Newton steps instead of IEEE sqrt and three divisions per interaction
+//   * 1/d by v_rsq_f64 and one third-order correction step instead of IEEE sqrt and three divisions per interaction
 //     (project.cu:634, 651-655): d = d2 * rsqrt(d2) + 1e-15 carries the reference's offset (it shifts the
 //     acceptance criterion of a near cell by up to 1e-9 relative, so it is kept), the criterion is the
 //     reference's `size / d < theta` in the form size < theta * d, and the force is G m_i M d_vec / (d2 * d) with
@@ -110,9 +110,12 @@ __global__ __launch_bounds__(kBlock) void walk_f64_kernel(
         const bool leaf = child < 0;                              // project.cu:623-626
         const double dx = cx - p.x, dy = cy - p.y;
         const double d2 = fma(dx, dx, dy * dy);
-        double y = __builtin_amdgcn_rsq(d2);                      // ~2^-26; two Newton steps: y = 1 / sqrt(d2) to ~1 ulp
-        y = fma(0.5 * y, fma(-(d2 * y), y, 1.0), y);
-        y = fma(0.5 * y, fma(-(d2 * y), y, 1.0), y);
+        // y = 1 / sqrt(d2): v_rsq_f64 is good to ~2^-26; with e = 1 - d2 y0^2 (|e| <~ 3e-8), 1 / sqrt(1 - e) =
+        // 1 + e/2 + 3 e^2 / 8 + O(e^3) -- ONE third-order step reaches fp64 rounding (the neglected term is
+        // 5 e^3 / 16 ~ 1e-23), five instructions instead of the eight of two Newton steps
+        const double y0 = __builtin_amdgcn_rsq(d2);
+        const double e = fma(-(d2 * y0), y0, 1.0);
+        const double y = fma(y0, e * fma(0.375, e, 0.5), y0);
         const double d = fma(d2, y, 1e-15);                       // sqrt(d2) + 1e-15, project.cu:634
         const bool accept = leaf || (size < theta * d);           // size / d < theta, project.cu:643
         bool self = false;
@@ -121,13 +124,16 @@ __global__ __launch_bounds__(kBlock) void walk_f64_kernel(
             if (COMPAT) self = self || ((int64_t)occ + 2 == -body);   // project.cu:646
         }
         const bool take = mine && accept && !self;
-        // M / (d2 * d):  1 / d2 = y * y,  1 / d = 1 / (sqrt(d2) + 1e-15) = y * (1 - 1e-15 * y) to second order
-        const double inv_d = fma(-1e-15 * y, y, y);
-        const double wgt = take ? m * (y * y) * inv_d : 0.0;
-        sx = fma(wgt, dx, sx);
-        sy = fma(wgt, dy, sy);
+        const uint64_t takem = __ballot(take);
+        if (takem != 0) {                                         // (a cell every lane opens: nine fp64 instructions saved)
+            // M / (d2 * d):  1 / d2 = y * y,  1 / d = 1 / (sqrt(d2) + 1e-15) = y * (1 - 1e-15 * y) to second order
+            const double inv_d = fma(-1e-15 * y, y, y);
+            const double wgt = take ? m * (y * y) * inv_d : 0.0;
+            sx = fma(wgt, dx, sx);
+            sy = fma(wgt, dy, sy);
+        }
         const uint64_t open = leaf ? 0ull : __ballot(mine && !accept);
-        if (STATS) { n_vis += __popcll(mask); ++n_wave; const uint64_t tm = __ballot(take); n_int += __popcll(tm); my_int += take ? 1u : 0u; }
+        if (STATS) { n_vis += __popcll(mask); ++n_wave; n_int += __popcll(takem); my_int += take ? 1u : 0u; }
         if (open != 0) {
             if (h_free) { h_idx = child; h_mask = open; h_free = false; }
             else push(child, open);

@@ -284,23 +284,68 @@ static void diag_subtree_force(const bho_node *nodes, int64_t start, int64_t i, 
     *ofx = fx; *ofy = fy;
 }
 
+/* every body below node `start` (itself excluded by `i`): the direct sum the device forms for a depth-cap cell */
+static uint32_t diag_subtree_direct(const bho_node *nodes, int64_t start, int64_t i, double px, double py,
+                                    double Gmi, int64_t **stack, int64_t *scap, double *ofx, double *ofy,
+                                    double *oabs)
+{
+    double fx = 0.0, fy = 0.0, fa = 0.0;
+    uint32_t cnt = 0;
+    int64_t top = 0;
+    (*stack)[top++] = start;
+    while (top > 0) {
+        const bho_node *q = &nodes[(*stack)[--top]];
+        if (q->mass <= 1e-15) continue;
+        int leaf = (q->child[0] == -1 && q->child[1] == -1 && q->child[2] == -1 && q->child[3] == -1);
+        if (leaf) {
+            if ((int64_t)q->particle == i) continue;
+            double dx = q->comx - px, dy = q->comy - py;
+            double d2 = dx * dx + dy * dy;
+            double d = sqrt(d2) + 1e-15;
+            double f = (Gmi * q->mass) / d2;
+            fx += f * (dx / d);
+            fy += f * (dy / d);
+            fa += f;
+            cnt++;
+            continue;
+        }
+        if (top + 4 > *scap) {
+            *scap *= 2;
+            *stack = (int64_t *)realloc(*stack, sizeof(int64_t) * (size_t)*scap);
+        }
+        for (int k = 0; k < 4; ++k) {
+            int64_t ci = (int64_t)q->child[k];
+            if (ci != -1) (*stack)[top++] = ci;
+        }
+    }
+    *ofx = fx; *ofy = fy; *oabs = fa;
+    return cnt;
+}
+
+/* cap_depth > 0 (uncapped trees only): a subdivided cell at that depth (root = 1) is treated as the device treats
+ * it when reference_compat is off -- a depth-cap BUCKET, summed body by body for every body that reaches it,
+ * whatever the acceptance criterion says (deviation iv) -- in forces[] and counts[];
+ * cap[i] (may be NULL) receives the summed magnitude of what that changes for body i against the plain walk. */
 void bho_compute_forces_diag(const bho_node *nodes, const double *pos, const double *mass,
                              int64_t lo, int64_t hi, double theta, double G, int compat_self_skip,
-                             int pos_rounded, double *forces, uint32_t *counts, double *abs_sum,
-                             double *coord, double *flip)
+                             int pos_rounded, int cap_depth, double *forces, uint32_t *counts, double *abs_sum,
+                             double *coord, double *flip, double *cap)
 {
     int64_t scap = 1024, *stack = (int64_t *)malloc(sizeof(int64_t) * scap);
+    int32_t *dstack = (int32_t *)malloc(sizeof(int32_t) * scap);
     int64_t scap2 = 1024, *stack2 = (int64_t *)malloc(sizeof(int64_t) * scap2);
     const double ulp23 = ldexp(1.0, -23);
     for (int64_t i = lo; i < hi; ++i) {
-        double fx = 0.0, fy = 0.0, asum = 0.0, csum = 0.0, fsum = 0.0;
+        double fx = 0.0, fy = 0.0, asum = 0.0, csum = 0.0, fsum = 0.0, capsum = 0.0;
         uint32_t cnt = 0;
         const double px = pos[2 * i], py = pos[2 * i + 1];
         const double pabs = pos_rounded ? fabs(px) + fabs(py) : 0.0;
         int64_t top = 0;
+        dstack[top] = 1;
         stack[top++] = 0;
         while (top > 0) {
             const int64_t qi = stack[--top];
+            const int32_t depth = dstack[top];
             const bho_node *q = &nodes[qi];
             double qm = q->mass;
             if (qm <= 1e-15) continue;
@@ -314,6 +359,17 @@ void bho_compute_forces_diag(const bho_node *nodes, const double *pos, const dou
             double ex = q->xmax - q->xmin, ey = q->ymax - q->ymin;
             double size = (ex > ey) ? ex : ey;
             const double cabs = fabs(q->comx) + fabs(q->comy) + pabs;
+            if (!leaf && cap_depth > 0 && depth == cap_depth) {
+                /* the device's bucket: every body of the cell, one by one */
+                double bx, by, ba, ox, oy;
+                const uint32_t bc = diag_subtree_direct(nodes, qi, i, px, py, G * mass[i], &stack2, &scap2, &bx, &by, &ba);
+                if (size / d < theta) { double f = (G * mass[i] * qm) / d2; ox = f * (dx / d); oy = f * (dy / d); }
+                else diag_subtree_force(nodes, qi, i, px, py, G * mass[i], theta, compat_self_skip, &stack2, &scap2, &ox, &oy);
+                capsum += sqrt((bx - ox) * (bx - ox) + (by - oy) * (by - oy));
+                fx += bx; fy += by; cnt += bc; asum += ba;
+                csum += pos_rounded ? ba * (cabs / d) : 0.0;
+                continue;
+            }
             if (!leaf) {
                 const double tol = ulp23 * (cabs / d + 4.0);
                 if (fabs(d - size / theta) <= d * tol) {
@@ -341,10 +397,11 @@ void bho_compute_forces_diag(const bho_node *nodes, const double *pos, const dou
                 if (top + 4 > scap) {
                     scap *= 2;
                     stack = (int64_t *)realloc(stack, sizeof(int64_t) * scap);
+                    dstack = (int32_t *)realloc(dstack, sizeof(int32_t) * scap);
                 }
                 for (int k = 0; k < 4; ++k) {
                     int64_t ci = (int64_t)q->child[k];
-                    if (ci != -1) stack[top++] = ci;
+                    if (ci != -1) { dstack[top] = depth + 1; stack[top++] = ci; }
                 }
             }
         }
@@ -354,8 +411,10 @@ void bho_compute_forces_diag(const bho_node *nodes, const double *pos, const dou
         if (abs_sum) abs_sum[i] = asum;
         if (coord) coord[i] = csum;
         if (flip) flip[i] = fsum;
+        if (cap) cap[i] = capsum;
     }
     free(stack);
+    free(dstack);
     free(stack2);
 }
 

@@ -65,11 +65,14 @@ void bho_compute_forces_range(const bho_node *nodes, const double *pos, const do
  * the fp32 parity tests: accepted-node count, sum of |F_j|, the part of it carried by differences of nearly equal
  * fp32 coordinates, and the total multipole error of the cells whose acceptance criterion an fp32 walk may
  * decide the other way ("borderline"; 0 = the fp32 walk must accept exactly this node set).  See bh_oracle.c.
- * Any of counts / abs_sum / coord / flip may be NULL.  All arrays are indexed by body like `forces`. */
+ * cap_depth > 0 (on an uncapped tree): subdivided cells at that depth (root = 1) are summed body by body, as the
+ * device's depth-cap buckets are (reference_compat off); cap[] tells how much that changed per body; with
+ * cap_depth == 0 the forces are the pinned walk's, bit for bit.
+ * Any of counts / abs_sum / coord / flip / cap may be NULL.  All arrays are indexed by body like `forces`. */
 void bho_compute_forces_diag(const bho_node *nodes, const double *pos, const double *mass,
                              int64_t lo, int64_t hi, double theta, double G, int compat_self_skip,
-                             int pos_rounded, double *forces, uint32_t *counts, double *abs_sum,
-                             double *coord, double *flip);
+                             int pos_rounded, int cap_depth, double *forces, uint32_t *counts, double *abs_sum,
+                             double *coord, double *flip, double *cap);
 
 /* main_approach_1.cpp:53-75: O(N^2) direct sum, no softening. */
 void bho_direct_forces(const double *pos, const double *mass, int64_t n, double G,

@@ -71,7 +71,7 @@ def lib() -> C.CDLL:
                                                C.c_double, C.c_int, dp, C.POINTER(_WalkStats)]
         L.bho_compute_forces_range.restype = None
         L.bho_compute_forces_diag.argtypes = [vp, dp, dp, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int,
-                                              C.c_int, dp, C.POINTER(C.c_uint32), dp, dp, dp]
+                                              C.c_int, C.c_int, dp, C.POINTER(C.c_uint32), dp, dp, dp, dp]
         L.bho_compute_forces_diag.restype = None
         L.bho_direct_forces.argtypes = [dp, dp, C.c_int64, C.c_double, dp]
         L.bho_direct_forces.restype = None
@@ -150,11 +150,13 @@ class WalkDiag:
     abs_sum: np.ndarray      # sum of |F_j| over accepted nodes
     coord: np.ndarray        # sum of |F_j| * (|comx| + |comy| (+ |px| + |py|)) / d_j
     flip: np.ndarray         # total multipole error of the borderline cells (0: the node set is unambiguous in fp32)
+    cap: np.ndarray          # cap_depth > 0: what summing the depth-cap cells body by body changed (magnitude)
 
 
 def compute_forces_diag(nodes, pos, mass, theta=0.5, G=6.67e-11, compat_self_skip=True, lo=0, hi=None,
-                        pos_rounded=False, threads=0) -> WalkDiag:
-    """threads > 1: the body range is split over that many Python threads (ctypes releases the GIL; bodies are
+                        pos_rounded=False, threads=0, cap_depth=0) -> WalkDiag:
+    """cap_depth > 0 (uncapped tree): cells at that depth are summed body by body like the device's depth-cap
+    buckets (forces and counts then follow the device's documented deviation, `cap` says by how much).  threads > 1: the body range is split over that many Python threads (ctypes releases the GIL; bodies are
     independent, the results do not depend on the split)."""
     pos, mass = _f64(pos), _f64(mass)
     nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
@@ -162,13 +164,13 @@ def compute_forces_diag(nodes, pos, mass, theta=0.5, G=6.67e-11, compat_self_ski
     hi = n if hi is None else hi
     f = np.zeros((n, 2))
     cnt = np.zeros(n, dtype=np.uint32)
-    asum, coord, flip = np.zeros(n), np.zeros(n), np.zeros(n)
+    asum, coord, flip, cap = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
     L = lib()
 
     def run(a, b):
         L.bho_compute_forces_diag(nodes.ctypes.data, _d(pos), _d(mass), a, b, theta, G, 1 if compat_self_skip else 0,
-                                  1 if pos_rounded else 0, _d(f), cnt.ctypes.data_as(C.POINTER(C.c_uint32)),
-                                  _d(asum), _d(coord), _d(flip))
+                                  1 if pos_rounded else 0, cap_depth, _d(f), cnt.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                  _d(asum), _d(coord), _d(flip), _d(cap))
     threads = threads or min(16, os.cpu_count() or 1)
     if threads <= 1 or hi - lo < 4096:
         run(lo, hi)
@@ -190,7 +192,7 @@ def compute_forces_diag(nodes, pos, mass, theta=0.5, G=6.67e-11, compat_self_ski
             t.start()
         for t in ts:
             t.join()
-    return WalkDiag(f, cnt, asum, coord, flip)
+    return WalkDiag(f, cnt, asum, coord, flip, cap)
 
 
 def direct_forces(pos, mass, G=6.67e-11) -> np.ndarray:
