@@ -389,8 +389,7 @@ def main():
         # not notice a stale or mis-routed LET.  A DISTRIBUTED DIRECT SUM does: every rank names 64 of its bodies,
         # the sample positions are all-gathered (W x 64 x 2 doubles), every rank sums the pull of ITS bodies on ALL
         # samples in fp64 (main_approach_1.cpp:53-75), one all_reduce(SUM) completes the sums, and each rank
-        # compares its own samples with what the forest walk gave them.  Barnes-Hut at theta 0.5 is within ~1e-2 of
-        # the direct sum; a missing or wrong remote tree is off by O(1).
+        # compares its own samples with what the forest walk gave them.  A missing or wrong remote tree is off by O(1).
         ns = 64
         pick = np.linspace(0, max(len(mf) - 1, 0), ns).astype(np.int64) if len(mf) else np.zeros(ns, dtype=np.int64)
         mine = torch.tensor(pf[pick] if len(mf) else np.zeros((ns, 2)), dtype=torch.float64)
@@ -416,13 +415,15 @@ def main():
             tot = tot.cpu()
         ref = tot.view(world, ns, 2)[rank].numpy()
         rerr = np.linalg.norm(acc[pick] - ref, axis=1) / np.linalg.norm(ref, axis=1) if len(mf) else np.zeros(ns)
-        chk = torch.tensor([float(np.median(rerr)), float(rerr.max())], dtype=torch.float64)
+        chk = torch.tensor([float(np.median(rerr)), float(np.quantile(rerr, 0.9))], dtype=torch.float64)
         if world > 1:
             chk = chk.to(dev) if a.backend == "nccl" else chk
             dist.all_reduce(chk, op=dist.ReduceOp.MAX)
             chk = chk.cpu()
+        # (the reference's own algorithm -- monopoles, theta 0.5 -- is within 1.3e-2 (median) / 4e-2 (95 %) of the
+        # direct sum, measured with the oracle; single bodies whose pulls cancel are off by more than their force)
         let_info["direct_sum_check"] = {"samples_per_rank": ns, "worst_rank_median_rel_err": float(chk[0]),
-                                        "max_rel_err": float(chk[1])}
+                                        "worst_rank_p90_rel_err": float(chk[1])}
         se.close()
 
         class _S:                                    # the fields the report below reads

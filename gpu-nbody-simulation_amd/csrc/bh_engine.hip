@@ -1318,11 +1318,10 @@ int bh_let_configure(bh_ctx *c, int32_t rank, int32_t world, int64_t let_cap, in
     } else {
         c->rank = rank; c->world = world;
         c->quads_local = c->internal_cap + 1;
-        const int64_t ntiles = blocks_for(c->quads_local, kTile);
         dev_free(c, c->qf);              // the single-tree node array: the forest below replaces it
         c->qf = nullptr;
         A(&c->needmask, (size_t)c->quads_local);
-        A(&c->let_tsum, (size_t)world * ntiles);
+        A(&c->let_tsum, (size_t)kMaxWorld);            // per-peer slot counters of the LET extraction
         A(&c->let_outidx, (size_t)world * c->quads_local);
         A(&c->lbounds, 4 * kLetBoxes); A(&c->all_bounds, 4 * kLetBoxes * (size_t)world);
         A(&c->acc_part, (size_t)std::max<int64_t>(c->cfg.capacity, 1));
@@ -1334,6 +1333,7 @@ int bh_let_configure(bh_ctx *c, int32_t rank, int32_t world, int64_t let_cap, in
     A(&c->let_send, (size_t)world * let_cap);
     if (rc) return rc;
     BH_HIP(c, hipMemset(c->let_ctr, 0, sizeof(LetCounters)));
+    BH_HIP(c, hipMemset(c->let_tsum, 0, kMaxWorld * sizeof(uint32_t)));
     c->let_mode = true;
     c->external_box = true;
     c->tree_valid = false;
@@ -1388,18 +1388,11 @@ int bh_let_build(bh_ctx *c)
     if (rc) return rc;
     (void)hipEventRecord(c->ev_let[1], st);
     const int64_t nq = c->quads_local;
-    const int ntiles = (int)blocks_for(nq, kTile);
-    hipLaunchKernelGGL(let_mark_kernel, dim3(blocks_for(nq, kBlock)), dim3(kBlock), 0, st, c->qf, c->all_bounds,
-                       c->world, c->rank, c->ctr, c->internal_cap, c->needmask);
-    hipLaunchKernelGGL(let_count_kernel, dim3(ntiles), dim3(kBlock), 0, st, c->needmask, c->world, c->ctr,
-                       c->internal_cap, c->let_tsum, ntiles);
-    hipLaunchKernelGGL(let_rowscan_kernel, dim3(c->world), dim3(kBlock), 0, st, c->let_tsum, ntiles, c->let_ctr,
-                       (uint32_t)c->let_cap, c->ctr, c->internal_cap);
-    hipLaunchKernelGGL(let_apply_kernel, dim3(ntiles), dim3(kBlock), 0, st, c->needmask, c->world, c->ctr,
-                       c->internal_cap, c->let_tsum, ntiles, c->let_outidx, nq);
+    hipLaunchKernelGGL(let_mark_alloc_kernel, dim3(blocks_for(nq, kBlock)), dim3(kBlock), 0, st, c->qf, c->all_bounds,
+                       c->world, c->rank, c->ctr, c->internal_cap, c->needmask, c->let_tsum, c->let_outidx, nq);
     hipLaunchKernelGGL(let_pack_kernel, dim3(blocks_for(nq, kBlock)), dim3(kBlock), 0, st, c->qf, c->needmask,
                        c->let_outidx, nq, c->world, c->rank, c->ctr, c->internal_cap, c->let_send,
-                       (uint32_t)c->let_cap, c->forest_base + (int64_t)c->rank * c->let_cap);
+                       (uint32_t)c->let_cap, c->forest_base + (int64_t)c->rank * c->let_cap, c->let_tsum, c->let_ctr);
     (void)hipEventRecord(c->ev_let[2], st);
     c->let_timed = true;
     BH_HIP(c, hipGetLastError());

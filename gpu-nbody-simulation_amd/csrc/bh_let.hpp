@@ -14,15 +14,19 @@
 //        dist^2(node COM, some box of q) <= (size/theta)^2 = thr
 //   (every body of q is at least that far away; a body opens a node iff d^2 <= thr).
 //
-// That test is local to the node, so marking is one pass over the quads with no traversal:
-//   let_mark   : needmask[child quad] = {peers that can open the parent node}   (64 peers max)
-//   let_count  : per (peer, tile) number of needed quads
-//   let_rowscan: per peer exclusive scan over tiles, total = LET size
-//   let_apply  : outidx[peer][quad] = position of the quad in that peer's LET
+// That test is local to the node, so the extraction is two passes over the quads with no traversal (round 3; rounds
+// 1-2 ran five: mark, count, row scan, apply, pack -- ~35 us of launch chain per step at 131k bodies per rank):
+//   let_mark_alloc: the thread of quad k decides, for each of its four nodes, which peers can open it -- that is the
+//                need mask of the node's CHILD quad -- and hands every (peer, child quad) pair its slot in that
+//                peer's LET: one counter per peer, one atomic per wave and peer (the lanes of a wave are ranked by
+//                ballots).  Slot 0 is the root quad's.  Which slot a quad gets depends on the order the waves
+//                arrive in; nothing else does -- a receiver follows child links, so its walk visits the same nodes
+//                in the same order and the forces are bit-identical run to run (tests/test_gpu_let.py).
 //   let_pack   : copy every needed quad into the peer's send block, child links rewritten to the
 //                RECEIVER's index space (its forest array places the LET of sender r at
 //                local_quads + r * let_cap), links to quads the peer cannot open cut (-1: the node
-//                is then always accepted by that peer's bodies), buckets turned into aggregates.
+//                is then always accepted by that peer's bodies), buckets turned into aggregates; its first
+//                workgroup also folds the counters into the running maxima / overflow flag and clears them.
 // (A quad whose ancestor chain is cut is packed but unreachable: a few percent of waste, no
 // traversal needed.)  Correctness does not depend on the domains being compact or disjoint --
 // only the LET sizes do.
@@ -124,11 +128,14 @@ __global__ __launch_bounds__(kWave) void let_local_bounds_kernel(const double *_
     }
 }
 
-// thread per local quad k in [0, n_quads): marks the CHILD quads of its four nodes
-__global__ __launch_bounds__(kBlock) void let_mark_kernel(const QuadF *__restrict__ qf,
-                                                           const double *__restrict__ all_bounds, int world,
-                                                           int rank, const TreeCounters *__restrict__ ctr,
-                                                           int64_t internal_cap, uint64_t *__restrict__ needmask)
+// thread per local quad k in [0, n_quads): need masks and LET slots of the CHILD quads of its four nodes
+// (slots[p] counts the quads peer p gets BEYOND the root quad, which is slot 0; let_pack_kernel clears it)
+__global__ __launch_bounds__(kBlock) void let_mark_alloc_kernel(const QuadF *__restrict__ qf,
+                                                                 const double *__restrict__ all_bounds, int world,
+                                                                 int rank, const TreeCounters *__restrict__ ctr,
+                                                                 int64_t internal_cap, uint64_t *__restrict__ needmask,
+                                                                 uint32_t *__restrict__ slots,
+                                                                 uint32_t *__restrict__ outidx, int64_t outidx_stride)
 {
     __shared__ float sbox[kMaxWorld * kLetBoxes][4];
     __shared__ float sall[kMaxWorld][4];                     // a peer's boxes taken together: a cheap first test
@@ -149,143 +156,63 @@ __global__ __launch_bounds__(kBlock) void let_mark_kernel(const QuadF *__restric
     }
     __syncthreads();
     const uint32_t total = ctr->n_internal;
-    if ((int64_t)total > internal_cap) return;
+    if ((int64_t)total > internal_cap) return;             // (uniform; let_pack_kernel raises the flag)
     const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (k > (int64_t)total) return;                       // quads 0..total
+    const bool live = k <= (int64_t)total;                 // quads 0..total
     const uint64_t everyone = (world >= 64 ? ~0ull : ((1ull << world) - 1)) & ~(1ull << rank);
-    if (k == 0) needmask[0] = everyone;                    // every peer gets the root
-    const QuadF q = qf[k];
+    if (k == 0) {                                          // every peer gets the root, in slot 0
+        needmask[0] = everyone;
+        for (int p = 0; p < world; ++p) outidx[(int64_t)p * outidx_stride] = 0u;
+    }
+    int32_t child[4] = {-1, -1, -1, -1};
+    uint64_t mask[4] = {0, 0, 0, 0};
+    if (live) {
+        const QuadF q = qf[k];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int32_t child = q.child[s];
-        if (child < 1) continue;                           // leaf, empty or bucket: no child quad
-        const float cx = q.xy[2 * s], cy = q.xy[2 * s + 1];
-        const float thr = q.thr[s] * 1.0001f;              // guard band for fp32 rounding of d^2
-        uint64_t mask = 0;
-        for (int p = 0; p < world; ++p) {
-            if (p == rank) continue;
-            {
-                const float dx = fmaxf(fmaxf(sall[p][0] - cx, cx - sall[p][1]), 0.f);
-                const float dy = fmaxf(fmaxf(sall[p][2] - cy, cy - sall[p][3]), 0.f);
-                if (!(dx * dx + dy * dy <= thr)) continue;     // out of reach of everything peer p holds
-            }
-            bool near = false;
+        for (int s = 0; s < 4; ++s) {
+            if (q.child[s] < 1) continue;                  // leaf, empty or bucket: no child quad
+            child[s] = q.child[s];
+            const float cx = q.xy[2 * s], cy = q.xy[2 * s + 1];
+            const float thr = q.thr[s] * 1.0001f;          // guard band for fp32 rounding of d^2
+            uint64_t m = 0;
+            for (int p = 0; p < world; ++p) {
+                if (p == rank) continue;
+                {
+                    const float dx = fmaxf(fmaxf(sall[p][0] - cx, cx - sall[p][1]), 0.f);
+                    const float dy = fmaxf(fmaxf(sall[p][2] - cy, cy - sall[p][3]), 0.f);
+                    if (!(dx * dx + dy * dy <= thr)) continue; // out of reach of everything peer p holds
+                }
+                bool near = false;
 #pragma unroll
-            for (int b = 0; b < kLetBoxes; ++b) {
-                const float *bx = sbox[p * kLetBoxes + b];
-                const float dx = fmaxf(fmaxf(bx[0] - cx, cx - bx[1]), 0.f);
-                const float dy = fmaxf(fmaxf(bx[2] - cy, cy - bx[3]), 0.f);
-                near = near || (dx * dx + dy * dy <= thr);     // an empty box (inf) gives inf: no
+                for (int b = 0; b < kLetBoxes; ++b) {
+                    const float *bx = sbox[p * kLetBoxes + b];
+                    const float dx = fmaxf(fmaxf(bx[0] - cx, cx - bx[1]), 0.f);
+                    const float dy = fmaxf(fmaxf(bx[2] - cy, cy - bx[3]), 0.f);
+                    near = near || (dx * dx + dy * dy <= thr); // an empty box (inf) gives inf: no
+                }
+                if (near) m |= 1ull << p;
             }
-            if (near) mask |= 1ull << p;
+            mask[s] = m;
+            needmask[child[s]] = m;
         }
-        needmask[child] = mask;
     }
-}
-
-// per (peer, tile): number of needed quads in the tile.  A thread owns kItems CONSECUTIVE quads, so its
-// count per peer is at most kItems and a tile's at most kTile = 2,048: four peers' counts travel in
-// the 16-bit fields of one 64-bit word and one block reduction serves four peers.
-__device__ __forceinline__ uint64_t let_packed_counts(const uint64_t (&m)[kItems], int p0)
-{
-    uint64_t c = 0;
+    // slots: per peer, the wave's pairs are ranked (child slot, then lane) and ONE lane draws the wave's share
+    const uint64_t lt = (1ull << lane_id()) - 1ull;
+    for (int p = 0; p < world; ++p) {
+        uint64_t b[4];
 #pragma unroll
-    for (int j = 0; j < kItems; ++j)
+        for (int s = 0; s < 4; ++s) b[s] = __ballot((mask[s] >> p) & 1ull);
+        const uint32_t tot = (uint32_t)(__popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]));
+        if (tot == 0) continue;                            // (uniform)
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(&slots[p], tot);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)base) + 1u;       // slot 0 is the root's
+        uint32_t before = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) c += ((m[j] >> (p0 + q)) & 1ull) << (16 * q);
-    return c;
-}
-
-__device__ __forceinline__ uint64_t block_exclusive_sum_u64(uint64_t v, uint64_t *smem, uint64_t &total)
-{
-    const uint64_t inc = wave_inclusive_sum(v);
-    const int l = lane_id();
-    if (l == kWave - 1) smem[wave_id()] = inc;
-    __syncthreads();
-    uint64_t base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < kWavesPerBlock; ++w) {
-        const uint64_t s = smem[w];
-        if (w < wave_id()) base += s;
-        tot += s;
-    }
-    __syncthreads();
-    total = tot;
-    return base + inc - v;
-}
-
-__global__ __launch_bounds__(kBlock) void let_count_kernel(const uint64_t *__restrict__ needmask, int world,
-                                                            const TreeCounters *__restrict__ ctr,
-                                                            int64_t internal_cap, uint32_t *__restrict__ tsum,
-                                                            int ntiles)
-{
-    __shared__ uint64_t sm[kWavesPerBlock + 1];
-    const uint32_t total = ctr->n_internal;
-    const int64_t nq = ((int64_t)total > internal_cap) ? 0 : (int64_t)total + 1;
-    const int64_t first = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kItems;
-    uint64_t m[kItems];
-#pragma unroll
-    for (int j = 0; j < kItems; ++j) m[j] = (first + j < nq) ? needmask[first + j] : 0ull;
-    for (int p0 = 0; p0 < world; p0 += 4) {
-        uint64_t tot;
-        (void)block_exclusive_sum_u64(let_packed_counts(m, p0), sm, tot);
-        if (threadIdx.x < 4 && p0 + (int)threadIdx.x < world)
-            tsum[(int64_t)(p0 + threadIdx.x) * ntiles + blockIdx.x] = (uint32_t)((tot >> (16 * threadIdx.x)) & 0xFFFFull);
-    }
-}
-
-// one workgroup per peer: exclusive scan of its tile counts; total = LET size
-__global__ __launch_bounds__(kBlock) void let_rowscan_kernel(uint32_t *__restrict__ tsum, int ntiles,
-                                                              LetCounters *lc, uint32_t let_cap,
-                                                              const TreeCounters *__restrict__ ctr,
-                                                              int64_t internal_cap)
-{
-    __shared__ uint32_t sm[kWavesPerBlock + 1];
-    uint32_t *row = tsum + (int64_t)blockIdx.x * ntiles;
-    uint32_t carry = 0;
-    for (int c0 = 0; c0 < ntiles; c0 += kBlock) {
-        const int b = c0 + threadIdx.x;
-        const uint32_t v = (b < ntiles) ? row[b] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_exclusive_sum(v, sm, tot);
-        if (b < ntiles) row[b] = carry + ex;
-        carry += tot;
-    }
-    if (threadIdx.x == 0) {
-        if (carry > lc->count[blockIdx.x]) lc->count[blockIdx.x] = carry;      // running maximum (one writer per peer)
-        if (carry > let_cap) lc->overflow = 1;
-        // a local tree that outgrew node_capacity leaves the send blocks untouched (let_mark / let_pack
-        // return early): the peers would walk the previous step's LET.  Report it where they look.
-        if (ctr->overflow || (int64_t)ctr->n_internal > internal_cap) lc->overflow = 1;
-    }
-}
-
-// outidx[peer][quad] = rank of the quad among the peer's needed quads (same blocked layout and packed
-// counters as let_count_kernel: world/4 block scans per tile instead of world * kItems)
-__global__ __launch_bounds__(kBlock) void let_apply_kernel(const uint64_t *__restrict__ needmask, int world,
-                                                            const TreeCounters *__restrict__ ctr,
-                                                            int64_t internal_cap, const uint32_t *__restrict__ tsum,
-                                                            int ntiles, uint32_t *__restrict__ outidx,
-                                                            int64_t outidx_stride)
-{
-    __shared__ uint64_t sm[kWavesPerBlock + 1];
-    const uint32_t total = ctr->n_internal;
-    const int64_t nq = ((int64_t)total > internal_cap) ? 0 : (int64_t)total + 1;
-    const int64_t first = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kItems;
-    uint64_t m[kItems];
-#pragma unroll
-    for (int j = 0; j < kItems; ++j) m[j] = (first + j < nq) ? needmask[first + j] : 0ull;
-    for (int p0 = 0; p0 < world; p0 += 4) {
-        uint64_t tot;
-        const uint64_t ex = block_exclusive_sum_u64(let_packed_counts(m, p0), sm, tot);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int p = p0 + q;
-            if (p >= world) break;
-            uint32_t o = tsum[(int64_t)p * ntiles + blockIdx.x] + (uint32_t)((ex >> (16 * q)) & 0xFFFFull);
-#pragma unroll
-            for (int j = 0; j < kItems; ++j)
-                if ((m[j] >> p) & 1ull) outidx[(int64_t)p * outidx_stride + first + j] = o++;
+        for (int s = 0; s < 4; ++s) {
+            if ((mask[s] >> p) & 1ull)
+                outidx[(int64_t)p * outidx_stride + child[s]] = base + before + (uint32_t)__popcll(b[s] & lt);
+            before += (uint32_t)__popcll(b[s]);
         }
     }
 }
@@ -297,9 +224,20 @@ __global__ __launch_bounds__(kBlock) void let_pack_kernel(const QuadF *__restric
                                                            int64_t outidx_stride, int world, int rank,
                                                            const TreeCounters *__restrict__ ctr,
                                                            int64_t internal_cap, QuadF *__restrict__ send,
-                                                           uint32_t let_cap, int64_t recv_base)
+                                                           uint32_t let_cap, int64_t recv_base,
+                                                           uint32_t *__restrict__ slots, LetCounters *lc)
 {
     const uint32_t total = ctr->n_internal;
+    if (blockIdx.x == 0 && (int)threadIdx.x < world) {
+        // this build's LET sizes -> running maxima and the sticky overflow flag; counters cleared for the next build
+        const uint32_t size = ((int)threadIdx.x == rank) ? 0u : 1u + slots[threadIdx.x];
+        slots[threadIdx.x] = 0u;
+        if (size > lc->count[threadIdx.x]) lc->count[threadIdx.x] = size;      // (one writer per peer)
+        if (size > let_cap) lc->overflow = 1;
+        // a local tree that outgrew node_capacity leaves the send blocks untouched (both kernels return early):
+        // the peers would walk the previous step's LET.  Report it where they look.
+        if (ctr->overflow || (int64_t)total > internal_cap) lc->overflow = 1;
+    }
     if ((int64_t)total > internal_cap) return;
     const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (k > (int64_t)total) return;
@@ -312,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void let_pack_kernel(const QuadF *__restric
     for (int p = 0; p < world; ++p) {
         if (!((mask >> p) & 1ull)) continue;
         const uint32_t o = outidx[(int64_t)p * outidx_stride + k];
-        if (o >= let_cap) continue;                       // overflow is flagged by let_rowscan
+        if (o >= let_cap) continue;                       // (overflow: flagged above)
         QuadF out = q;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -320,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void let_pack_kernel(const QuadF *__restric
             if (c >= 1) {
                 // child quad needed by p -> its slot in p's forest; otherwise cut: p's bodies all
                 // accept this node (d^2 > thr for every point of p's box)
-                // (a slot past let_cap -- overflow, flagged by let_rowscan -- is cut too, so that a
+                // (a slot past let_cap -- overflow, flagged above -- is cut too, so that a
                 // receiver that walks before the host has seen the flag never leaves its block)
                 int32_t link = -1;
                 if ((cmask[s] >> p) & 1ull) {

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--partition", choices=["hilbert", "orb", "orb-nosnap"], default="orb")
     ap.add_argument("--theta", type=float, default=0.5)
     ap.add_argument("--precision", choices=["f32", "mixed"], default="f32")
+    ap.add_argument("--graph", action="store_true", help="also replay each rank's chain from a captured hipGraph")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     n = a.n
@@ -130,9 +131,33 @@ def main():
                     chain()
                 e.sync()
                 acc.append((time.perf_counter() - t0) / a.reps * 1e3)
+        # the same chain replayed from a hipGraph (one launch of ~14 kernel nodes instead of ~14 launches): does the
+        # host-side launch path or the GPU-side boundary between dependent kernels set a rank's step time?
+        letg = []
+        if a.graph:
+            for e in engs:
+                st = torch.cuda.Stream()
+                e.sync()
+                e.set_stream(st.cuda_stream)
+                g = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(g, stream=st, capture_error_mode="relaxed"):
+                        e.let_bounds(); e.let_build(); e.let_forces()
+                    for _ in range(3):
+                        g.replay()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(a.reps):
+                        g.replay()
+                    torch.cuda.synchronize()
+                    letg.append((time.perf_counter() - t0) / a.reps * 1e3)
+                except Exception as ex:                       # noqa: BLE001 -- report, the eager numbers stand
+                    print("graph capture failed:", repr(ex)[:200], flush=True)
+                    break
         for e in engs:
             e.close()
         row = {"world": world, "replicated_ms_max": max(rep), "let_ms_max": max(let), "let_ms_mean": float(np.mean(let)),
+               "let_graph_ms_max": max(letg) if len(letg) == len(engs) else None,
                "let_two_launch_ms_max": max(let2), "let_two_launch_ms_mean": float(np.mean(let2)),
                "let_quads_mean": float(counts[counts > 0].mean()), "let_quads_max": int(counts.max()),
                "let_cap": cap, "all_to_all_bytes_per_rank": cap * 80 * (world - 1),

@@ -104,7 +104,7 @@ def test_bench_exchange_path_on_real_rccl_single_rank(tmp_path):
             assert all(ph["max_over_ranks"][k] >= 0 for k in names) and ph["max_over_ranks"]["build_let"] > 0
             assert ph["max_over_ranks"]["let_tree_last_step"] > 0 and ph["max_over_ranks"]["let_pack_last_step"] > 0
             chk = d["let"]["direct_sum_check"]            # the forest against a distributed fp64 direct sum
-            assert chk["worst_rank_median_rel_err"] < 1e-2 and chk["max_rel_err"] < 0.2
+            assert chk["worst_rank_median_rel_err"] < 3e-2 and chk["worst_rank_p90_rel_err"] < 0.15
 
 
 def test_bench_let_path_with_three_ranks_sharing_the_gpu(tmp_path):
@@ -137,7 +137,7 @@ def test_bench_let_path_with_three_ranks_sharing_the_gpu(tmp_path):
     assert d["let"]["net_force_over_sum_abs_force"] < 2e-3
     # ... and the forces every rank computed from the others' trees agree with a DISTRIBUTED fp64 direct sum
     # (a stale, zero or mis-routed LET would be off by O(1); Newton's third law alone would not notice)
-    assert d["let"]["direct_sum_check"]["worst_rank_median_rel_err"] < 1e-2 and d["let"]["direct_sum_check"]["max_rel_err"] < 0.2
+    assert d["let"]["direct_sum_check"]["worst_rank_median_rel_err"] < 3e-2 and d["let"]["direct_sum_check"]["worst_rank_p90_rel_err"] < 0.15
     assert d["rccl"] == {"world_size": 3, "backend": "gloo"} and d["phases"]["steps_profiled"] == 3
     assert abs(d["let"]["bodies_on_rank0"] - 65536 / 3) < 0.15 * 65536 / 3
     r0 = subprocess.run([sys.executable] + base + ["--force-sharded"], capture_output=True, text=True, timeout=600, env=env)
