@@ -478,28 +478,40 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
     const bool want_partial = integrate && !to_sorted && lo == 0 && hi == c->n;
     double *partial = want_partial ? c->partial : nullptr;
     int per_partial = kBlock;
+    // N_THREADS (project.cu:5-7, 703: `body_i += N_THREADS`): at most that many bodies are walked at a time -- the
+    // range is taken in passes of n_threads bodies, rounded up to whole 256-thread workgroups, one launch after the
+    // other on the stream, as the reference's threads take their bodies one after the other.  0 (the default):
+    // one pass.  It gives the thread axis of the reference's first scaling experiment (first_scaling_script.sh:
+    // 17-36) a meaning on this hardware: n_threads = 1 is one workgroup at a time.
+    const int64_t pass = c->cfg.n_threads > 0 ? ((int64_t)c->cfg.n_threads + kBlock - 1) / kBlock * kBlock : hi - lo;
     if (c->exact && c->fast64) {
-        const unsigned grid = blocks_for(hi - lo, kBlock);
         if (stats && !c->body_counts) { int rc = dev_alloc(c, &c->body_counts, (size_t)std::max<int64_t>(c->cfg.capacity, 1)); if (rc) return rc; }
-        auto args = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, c->stream, c->gd, c->ld, c->perm,
-                               (double2 *)c->pos, (double2 *)c->vel, (const double *)c->mass,
-                               (double2 *)c->force, lo, hi, c->cfg.theta, c->cfg.G, c->cfg.dt,
-                               integrate ? 1 : 0, c->ctr, partial, stats ? c->body_counts : nullptr);
-        };
-        if (c->compat) { if (stats) args(walk_f64_kernel<true, true>); else args(walk_f64_kernel<true, false>); }
-        else           { if (stats) args(walk_f64_kernel<false, true>); else args(walk_f64_kernel<false, false>); }
+        for (int64_t plo = lo; plo < hi; plo += pass) {
+            const int64_t phi = std::min(hi, plo + pass);
+            double *pp = partial ? partial + 4 * ((plo - lo) / kBlock) : nullptr;
+            auto args = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(blocks_for(phi - plo, kBlock)), dim3(kBlock), 0, c->stream, c->gd, c->ld, c->perm,
+                                   (double2 *)c->pos, (double2 *)c->vel, (const double *)c->mass,
+                                   (double2 *)c->force, plo, phi, c->cfg.theta, c->cfg.G, c->cfg.dt,
+                                   integrate ? 1 : 0, c->ctr, pp, stats ? c->body_counts : nullptr);
+            };
+            if (c->compat) { if (stats) args(walk_f64_kernel<true, true>); else args(walk_f64_kernel<true, false>); }
+            else           { if (stats) args(walk_f64_kernel<false, true>); else args(walk_f64_kernel<false, false>); }
+        }
         BH_HIP(c, hipGetLastError());
     } else if (c->exact) {
-        const unsigned grid = blocks_for(hi - lo, kBlock);
-        auto args = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, c->stream, c->gd, c->ld, c->perm,
-                               (double2 *)c->pos, (double2 *)c->vel, (const double *)c->mass,
-                               (double2 *)c->force, lo, hi, c->cfg.theta, c->cfg.G, c->cfg.dt,
-                               integrate ? 1 : 0, c->ctr, partial);
-        };
-        if (c->compat) { if (stats) args(walk_exact_kernel<true, true>); else args(walk_exact_kernel<true, false>); }
-        else           { if (stats) args(walk_exact_kernel<false, true>); else args(walk_exact_kernel<false, false>); }
+        for (int64_t plo = lo; plo < hi; plo += pass) {
+            const int64_t phi = std::min(hi, plo + pass);
+            double *pp = partial ? partial + 4 * ((plo - lo) / kBlock) : nullptr;
+            auto args = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(blocks_for(phi - plo, kBlock)), dim3(kBlock), 0, c->stream, c->gd, c->ld, c->perm,
+                                   (double2 *)c->pos, (double2 *)c->vel, (const double *)c->mass,
+                                   (double2 *)c->force, plo, phi, c->cfg.theta, c->cfg.G, c->cfg.dt,
+                                   integrate ? 1 : 0, c->ctr, pp);
+            };
+            if (c->compat) { if (stats) args(walk_exact_kernel<true, true>); else args(walk_exact_kernel<true, false>); }
+            else           { if (stats) args(walk_exact_kernel<false, true>); else args(walk_exact_kernel<false, false>); }
+        }
         BH_HIP(c, hipGetLastError());
     } else {
         WalkFastArgs a{};
@@ -532,7 +544,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         // (scripts/split_ab.sh): 8 up to 32k bodies per launch, 4 up to ~100k, one wave
         // per group -- the hand-scheduled loop with two quads in flight -- beyond (round 1's compiled loop
         // lost to the split walk up to 192k; at 131k: 0.097 against 0.102 ms).  BH_WALK_SPLIT overrides (1 = off).
-        int split = (c->cfg.flags & BH_FLAG_WALK_NO_SPLIT) ? 1 : c->walk_split;
+        int split = (c->cfg.flags & BH_FLAG_WALK_NO_SPLIT) || c->cfg.n_threads > 0 ? 1 : c->walk_split;   // (n_threads: one thread per body)
         if (split <= 0) {
             const int64_t groups = (hi - lo + kWave - 1) / kWave;
             // (a forest walk keeps the split longer: the level-synchronous walk seeds its first frontier with
@@ -548,8 +560,12 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         const int64_t forest_quads = c->let_mode ? c->forest_base + (int64_t)c->world * c->let_cap : c->internal_cap + 1;
         const bool use_asm = c->walk_asm && !(c->cfg.flags & BH_FLAG_WALK_PORTABLE) &&
                              forest_quads * (int64_t)sizeof(QuadF) < (1ll << 31) && c->n < (1ll << 28);
-        BH_HIP(c, launch_walk_fast(a, lds, stats, split, use_asm, c->stream));
         if (walk_fast_split_effective(a, lds, split)) per_partial = kWave;
+        for (int64_t plo = lo; plo < hi; plo += pass) {
+            a.lo = plo; a.hi = std::min(hi, plo + pass);
+            a.partial = partial ? partial + 4 * ((plo - lo) / per_partial) : nullptr;
+            BH_HIP(c, launch_walk_fast(a, lds, stats, split, use_asm, c->stream));
+        }
     }
     if (want_partial) c->partial_count = (int)blocks_for(hi - lo, per_partial);
     if (!c->exact && lo == 0 && hi == c->n) c->group_cost_valid = true;

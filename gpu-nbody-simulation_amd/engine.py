@@ -47,7 +47,7 @@ class BhConfig:
     precision: Precision = Precision.F64_EXACT
     reference_compat: bool = True
     device: int = 0
-    n_threads: int = 0              # N_THREADS, project.cu:5-7 (accepted, not used)
+    n_threads: int = 0              # N_THREADS, project.cu:5-7: bodies walked at a time (passes of whole workgroups); 0 = all
     flags: int = 0
     node_capacity: int = 0
 

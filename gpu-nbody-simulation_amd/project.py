@@ -161,7 +161,10 @@ def _parse(argv):
     ap.add_argument("-o", dest="ignored_output", help="accepted and ignored (nvcc line compatibility)")
     ap.add_argument("source", nargs="?", help="accepted and ignored (nvcc line compatibility)")
     a = ap.parse_args(argv)
-    macros = {"N_BODIES": 1000 * 40, "N_THREADS": 1024, "N_SIMULATIONS": 10}   # project.cu:1-11
+    # project.cu:1-11.  N_THREADS: the reference's default is 1,024 CUDA threads striding over the bodies; here it
+    # caps the bodies walked at a time ONLY when given (-DN_THREADS=... / --n-threads, as the scaling scripts do):
+    # unset, a step walks all bodies in one launch.
+    macros = {"N_BODIES": 1000 * 40, "N_THREADS": 0, "N_SIMULATIONS": 10}
     for d in a.D:
         k, _, v = d.partition("=")
         if k not in macros:

@@ -104,7 +104,7 @@ def plot(rows, png_path):
         ax.plot(range(len(sel)), [r["body_steps_per_s"] for r in sel], marker="o", label=f"N={nb}")
         ax.set_xticks(range(len(sel)))
         ax.set_xticklabels([r["n_threads"] for r in sel])
-    ax.set_xlabel("n_threads (accepted, not used by the CDNA4 launch shape)")
+    ax.set_xlabel("n_threads (bodies walked at a time: passes of whole 256-thread workgroups)")
     ax.set_ylabel("body-steps / s (device time)")
     ax.set_yscale("log")
     ax.legend()

@@ -98,9 +98,11 @@ typedef struct bh_config {
                                    by body (bucket leaf), so no body interacts with its own
                                    cell; larger cells (degenerate inputs) are aggregated.     */
     int32_t  device;            /* HIP device ordinal                                       */
-    int32_t  n_threads;         /* N_THREADS, project.cu:5-7.  Accepted so the scaling
-                                   scripts' parameter has somewhere to go; the CDNA4 launch
-                                   shape does not depend on it (a12 is replaced, not kept).  */
+    int32_t  n_threads;         /* N_THREADS, project.cu:5-7, 703: at most this many bodies are walked
+                                   at a time (rounded up to whole 256-thread workgroups; the passes run
+                                   one after the other, as the reference's threads stride over the bodies).
+                                   0 = all at once.  The launch SHAPE within a pass is CDNA4's, not the
+                                   reference's (a12 is replaced, not kept).                              */
     uint32_t flags;             /* BH_FLAG_*                                                */
     int64_t  node_capacity;     /* 0 = automatic (8*capacity + 1024 nodes)                  */
 } bh_config;

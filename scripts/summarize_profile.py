@@ -8,10 +8,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from gpu_nbody_simulation_amd.build import source_digest  # noqa: E402
 
 src, dst = sys.argv[1], sys.argv[2]
+update_latest = "--no-latest" not in sys.argv[3:]          # other configurations than the headline: keep profiles/latest_*
 os.makedirs(dst, exist_ok=True)
 latest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
 shutil.copy(latest(f"{src}/trace/runc/*_kernel_stats.csv"), f"{dst}/kernel_stats.csv")
-shutil.copy(f"{src}/bench.json", f"{dst}/bench.json")
+if os.path.exists(f"{src}/bench.json"):
+    shutil.copy(f"{src}/bench.json", f"{dst}/bench.json")
 rows = []
 for d in sorted(glob.glob(f"{src}/pmc*/")):
     f = latest(f"{d}runc/*_counter_collection.csv")
@@ -45,6 +47,7 @@ if "FETCH_SIZE" in walk and "WRITE_SIZE" in walk:
          "source_digest": source_digest(),
          "git_head": subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None}
     json.dump(t, open(f"{dst}/walk_traffic.json", "w"), indent=1)
-    json.dump(t, open(os.path.join(os.path.dirname(dst.rstrip("/")), "latest_walk_traffic.json"), "w"), indent=1)
+    if update_latest:
+        json.dump(t, open(os.path.join(os.path.dirname(dst.rstrip("/")), "latest_walk_traffic.json"), "w"), indent=1)
     print(json.dumps(t))
 print(open(f"{dst}/kernel_stats.csv").read()[:1800])

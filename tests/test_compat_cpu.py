@@ -52,7 +52,7 @@ def test_project_argument_parsing():
     a, mac = project._parse(["-DN_BODIES=1000 * 40", "-DN_THREADS=32", "-o", "project", "project.cu"])
     assert mac == {"N_BODIES": 40000, "N_THREADS": 32, "N_SIMULATIONS": 10}        # project.cu:1-11
     a, mac = project._parse([])
-    assert mac == {"N_BODIES": 40000, "N_THREADS": 1024, "N_SIMULATIONS": 10}
+    assert mac == {"N_BODIES": 40000, "N_THREADS": 0, "N_SIMULATIONS": 10}         # N_THREADS unset: all bodies at once
     assert project._macro_value("(1000 * 40)") == 40000 and project._macro_value(" 7 ") == 7
     # macro values are parsed, never evaluated: anything but integers and `*` is refused
     for bad in ("().__class__", "__import__('os')", "2**3", "1+1", "0x10", ""):

@@ -40,7 +40,8 @@ TOL_C4 = (1.0e-6, 1.75e-4, 1.5e-3)
 TOL_C5 = (3.5e-6, 7.6e-4, 1.4e-2)
 # theta 0.3 at N = 65,536, measured (seed 1): fp32 2.7e-7 / 2.2e-5 / 1.7e-4 (uniform), 1.8e-7 / 1.0e-5 / 6.3e-5 (Plummer);
 # mixed 8.0e-7 / 5.4e-5 / 3.4e-4 and 4.4e-7 / 3.2e-5 / 3.2e-4
-TOL_65K = {G.Precision.F32: (5.4e-7, 4.4e-5, 3.4e-4), G.Precision.MIXED: (1.6e-6, 1.1e-4, 6.8e-4)}
+# (the maximum is one body's value and moves with the seed: 6.9e-4 with this test's seed 7 in mixed precision)
+TOL_65K = {G.Precision.F32: (5.4e-7, 4.4e-5, 3.4e-4), G.Precision.MIXED: (1.6e-6, 1.1e-4, 1.4e-3)}
 SAMPLE = 65536
 
 

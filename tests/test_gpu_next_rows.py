@@ -91,6 +91,27 @@ def test_reference_scaling_script_lines_run_unchanged(tmp_path):
     assert os.path.getsize(tmp_path / "quadtree_init_gpu.txt") > 0
 
 
+@pytest.mark.parametrize("precision", [G.Precision.F64_EXACT, G.Precision.F32, G.Precision.F64])
+def test_n_threads_limits_the_bodies_walked_at_a_time_and_changes_no_result(precision, init1024):
+    """N_THREADS (project.cu:5-7, 703): the walk takes the bodies in passes of n_threads (whole 256-thread workgroups),
+    one launch after the other -- the axis of the reference's first scaling experiment (first_scaling_script.sh:17-36).
+    Same bodies, same tree, same per-body sums: results bitwise equal for every n_threads; the time is not."""
+    m, p, v = init1024
+    if precision == G.Precision.F32:
+        m, p, v = (x.astype(np.float32).astype(np.float64) for x in (m, p, v))
+    out, ms = [], []
+    for nt in (0, 1, 300, 1024):
+        with G.BarnesHutEngine(G.BhConfig(capacity=1024, precision=precision, n_threads=nt,
+                                          max_depth=10 if precision != G.Precision.F32 else 16)) as e:
+            e.upload(p, v, m)
+            e.step(3)
+            out.append(e.download())
+            ms.append(e.stats().walk_ms)
+    for pp, vv in out[1:]:
+        assert np.array_equal(pp, out[0][0]) and np.array_equal(vv, out[0][1])
+    assert ms[1] > 1.5 * ms[0]                   # one workgroup at a time (4 passes) against all four at once
+
+
 def test_overflow_is_reported_by_sync_after_step():
     r = np.random.default_rng(0)
     n = 4096
