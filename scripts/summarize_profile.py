@@ -32,7 +32,9 @@ with open(f"{dst}/pmc_summary.csv", "w", newline="") as fh:
 # WRITE_SIZE are in KB, collected in separate --pmc passes; on gfx950 FETCH_SIZE reports exactly 1/2
 # of the bytes read -- calibrated for THIS kernel's access pattern (wave-uniform 64-byte scalar
 # loads) with scripts/calib/fetch_calib.hip: ratio 0.50003 -- so reads = 2 * FETCH_SIZE.
-walk = {c: v for (k, c, n, v) in rows if k.startswith("void bh::walk_fast_kernel<false, false, 1, true>")}
+# the product walk of the run: the hand-scheduled kernel, or the C++ loop where the engine had to fall back to it
+walk = {c: v for (k, c, n, v) in rows if k.startswith("void bh::walk_fast_kernel<false, false, 1, true>")} or \
+       {c: v for (k, c, n, v) in rows if k.startswith("void bh::walk_fast_kernel<false, false, 1, false>")}
 calib = {}
 for f in glob.glob(f"{src}/calib/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import bh_oracle as O  # noqa: E402
 import gpu_nbody_simulation_amd as G  # noqa: E402
+from gpu_nbody_simulation_amd.engine import FLAG_WALK_NO_SPLIT  # noqa: E402
 from gpu_nbody_simulation_amd import project, scaling, textio  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -101,7 +102,9 @@ def test_n_threads_limits_the_bodies_walked_at_a_time_and_changes_no_result(prec
         m, p, v = (x.astype(np.float32).astype(np.float64) for x in (m, p, v))
     out, ms = [], []
     for nt in (0, 1, 300, 1024):
-        with G.BarnesHutEngine(G.BhConfig(capacity=1024, precision=precision, n_threads=nt,
+        # (fp32: one wavefront per 64 bodies on both sides -- a pass is one thread per body; without the cap a launch
+        # this small would let 8 wavefronts share each group, another order of the fp32 sums)
+        with G.BarnesHutEngine(G.BhConfig(capacity=1024, precision=precision, n_threads=nt, flags=FLAG_WALK_NO_SPLIT,
                                           max_depth=10 if precision != G.Precision.F32 else 16)) as e:
             e.upload(p, v, m)
             e.step(3)
