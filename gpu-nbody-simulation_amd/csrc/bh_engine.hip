@@ -556,10 +556,13 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
             split = groups <= (c->let_mode ? 512 : 768) ? 8 : groups <= 3072 ? 4 : 1;
         }
         if (3 * c->Dm + 2 > kWave) split = 1;        // the level-synchronous walk's depth-first fallback has 64 entries
-        // hand-scheduled loop: byte offsets into the quad array and the sorted bodies are 32-bit there
+        // hand-scheduled loop: byte offsets into the quad array and the sorted bodies are 32-bit there, and the SGPR
+        // offset of s_load is an UNSIGNED 32-bit value on gfx950 (scripts/calib/soffset_calib.hip, profiles/r03_final/
+        // soffset_calib.txt: offsets up to 0xf0000100 read base + offset): 4 GiB of quads = 53.6 M.  (Round 2 stopped at
+        // 2 GiB, so BASELINE config 5 -- capacity 33.5 M quads -- ran the C++ loop.)
         const int64_t forest_quads = c->let_mode ? c->forest_base + (int64_t)c->world * c->let_cap : c->internal_cap + 1;
         const bool use_asm = c->walk_asm && !(c->cfg.flags & BH_FLAG_WALK_PORTABLE) &&
-                             forest_quads * (int64_t)sizeof(QuadF) < (1ll << 31) && c->n < (1ll << 28);
+                             forest_quads * (int64_t)sizeof(QuadF) < (1ll << 32) && c->n < (1ll << 28);
         if (walk_fast_split_effective(a, lds, split)) per_partial = kWave;
         for (int64_t plo = lo; plo < hi; plo += pass) {
             a.lo = plo; a.hi = std::min(hi, plo + pass);
@@ -1404,7 +1407,7 @@ int bh_let_build(bh_ctx *c)
     if (rc) return rc;
     (void)hipEventRecord(c->ev_let[1], st);
     const int64_t nq = c->quads_local;
-    hipLaunchKernelGGL(let_mark_alloc_kernel, dim3(blocks_for(nq, kBlock)), dim3(kBlock), 0, st, c->qf, c->all_bounds,
+    hipLaunchKernelGGL(let_mark_alloc_kernel, dim3(blocks_for(4 * nq, kBlock)), dim3(kBlock), 0, st, c->qf, c->all_bounds,
                        c->world, c->rank, c->ctr, c->internal_cap, c->needmask, c->let_tsum, c->let_outidx, nq);
     hipLaunchKernelGGL(let_pack_kernel, dim3(blocks_for(nq, kBlock)), dim3(kBlock), 0, st, c->qf, c->needmask,
                        c->let_outidx, nq, c->world, c->rank, c->ctr, c->internal_cap, c->let_send,

@@ -128,8 +128,11 @@ __global__ __launch_bounds__(kWave) void let_local_bounds_kernel(const double *_
     }
 }
 
-// thread per local quad k in [0, n_quads): need masks and LET slots of the CHILD quads of its four nodes
-// (slots[p] counts the quads peer p gets BEYOND the root quad, which is slot 0; let_pack_kernel clears it)
+// ONE LANE PER NODE (four lanes per local quad k in [0, n_quads)): the need mask and the LET slots of the node's CHILD
+// quad.  (One thread per quad walked its four nodes x W peers x 9 boxes in sequence: 18.6 us at 94k quads, the
+// second-longest kernel of a rank's step at 135k bodies; the launch is far too small to fill the GPU, so its time is
+// the length of one thread's chain.)  slots[p] counts the quads peer p gets BEYOND the root quad, which is slot 0;
+// let_pack_kernel clears it.
 __global__ __launch_bounds__(kBlock) void let_mark_alloc_kernel(const QuadF *__restrict__ qf,
                                                                  const double *__restrict__ all_bounds, int world,
                                                                  int rank, const TreeCounters *__restrict__ ctr,
@@ -157,24 +160,23 @@ __global__ __launch_bounds__(kBlock) void let_mark_alloc_kernel(const QuadF *__r
     __syncthreads();
     const uint32_t total = ctr->n_internal;
     if ((int64_t)total > internal_cap) return;             // (uniform; let_pack_kernel raises the flag)
-    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t node = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // node id = 4 * quad + slot
+    const int64_t k = node >> 2;
+    const int sl = (int)(node & 3);
     const bool live = k <= (int64_t)total;                 // quads 0..total
     const uint64_t everyone = (world >= 64 ? ~0ull : ((1ull << world) - 1)) & ~(1ull << rank);
-    if (k == 0) {                                          // every peer gets the root, in slot 0
+    if (node == 0) {                                       // every peer gets the root, in slot 0
         needmask[0] = everyone;
         for (int p = 0; p < world; ++p) outidx[(int64_t)p * outidx_stride] = 0u;
     }
-    int32_t child[4] = {-1, -1, -1, -1};
-    uint64_t mask[4] = {0, 0, 0, 0};
+    int32_t child = -1;
+    uint64_t mask = 0;
     if (live) {
-        const QuadF q = qf[k];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (q.child[s] < 1) continue;                  // leaf, empty or bucket: no child quad
-            child[s] = q.child[s];
-            const float cx = q.xy[2 * s], cy = q.xy[2 * s + 1];
-            const float thr = q.thr[s] * 1.0001f;          // guard band for fp32 rounding of d^2
-            uint64_t m = 0;
+        const QuadF *q = qf + k;
+        child = q->child[sl];
+        if (child >= 1) {                                  // (leaf, empty or bucket: no child quad)
+            const float cx = q->xy[2 * sl], cy = q->xy[2 * sl + 1];
+            const float thr = q->thr[sl] * 1.0001f;        // guard band for fp32 rounding of d^2
             for (int p = 0; p < world; ++p) {
                 if (p == rank) continue;
                 {
@@ -190,30 +192,20 @@ __global__ __launch_bounds__(kBlock) void let_mark_alloc_kernel(const QuadF *__r
                     const float dy = fmaxf(fmaxf(bx[2] - cy, cy - bx[3]), 0.f);
                     near = near || (dx * dx + dy * dy <= thr); // an empty box (inf) gives inf: no
                 }
-                if (near) m |= 1ull << p;
+                if (near) mask |= 1ull << p;
             }
-            mask[s] = m;
-            needmask[child[s]] = m;
-        }
+            needmask[child] = mask;
+        } else child = -1;
     }
-    // slots: per peer, the wave's pairs are ranked (child slot, then lane) and ONE lane draws the wave's share
+    // slots: per peer, the wave's nodes are ranked by lane and ONE lane draws the wave's share
     const uint64_t lt = (1ull << lane_id()) - 1ull;
     for (int p = 0; p < world; ++p) {
-        uint64_t b[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) b[s] = __ballot((mask[s] >> p) & 1ull);
-        const uint32_t tot = (uint32_t)(__popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]));
-        if (tot == 0) continue;                            // (uniform)
+        const uint64_t b = __ballot((mask >> p) & 1ull);
+        if (b == 0) continue;                              // (uniform)
         uint32_t base = 0;
-        if (lane_id() == 0) base = atomicAdd(&slots[p], tot);
+        if (lane_id() == 0) base = atomicAdd(&slots[p], (uint32_t)__popcll(b));
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)base) + 1u;       // slot 0 is the root's
-        uint32_t before = 0;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if ((mask[s] >> p) & 1ull)
-                outidx[(int64_t)p * outidx_stride + child[s]] = base + before + (uint32_t)__popcll(b[s] & lt);
-            before += (uint32_t)__popcll(b[s]);
-        }
+        if ((mask >> p) & 1ull) outidx[(int64_t)p * outidx_stride + child] = base + (uint32_t)__popcll(b & lt);
     }
 }
 

@@ -838,7 +838,8 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
                         }
                     }
                     const QuadRegs A = load_quad(quads + bA);
-                    const QuadRegs B = load_quad(quads + (bB >= 0 ? bB : 0));
+                    QuadRegs B = A;
+                    if (bB >= 0) B = load_quad(quads + bB);         // (both in flight before A is evaluated)
                     h_free = true; h_idx = -1;
                     eval_quad(A, mA);
                     na = h_idx; nam = h_mask;
