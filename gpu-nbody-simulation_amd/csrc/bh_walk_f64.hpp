@@ -113,7 +113,11 @@ __global__ __launch_bounds__(kBlock) void walk_f64_kernel(
         // y = 1 / sqrt(d2): v_rsq_f64 is good to ~2^-26; with e = 1 - d2 y0^2 (|e| <~ 3e-8), 1 / sqrt(1 - e) =
         // 1 + e/2 + 3 e^2 / 8 + O(e^3) -- ONE third-order step reaches fp64 rounding (the neglected term is
         // 5 e^3 / 16 ~ 1e-23), five instructions instead of the eight of two Newton steps
+#if defined(BH_F64_RSQ32) && BH_F64_RSQ32
+        const double y0 = (double)__builtin_amdgcn_rsqf((float)d2);     // A/B: fp32 seed (2^-23) -- the same step still reaches 1e-20
+#else
         const double y0 = __builtin_amdgcn_rsq(d2);
+#endif
         const double e = fma(-(d2 * y0), y0, 1.0);
         const double y = fma(y0, e * fma(0.375, e, 0.5), y0);
         const double d = fma(d2, y, 1e-15);                       // sqrt(d2) + 1e-15, project.cu:634
