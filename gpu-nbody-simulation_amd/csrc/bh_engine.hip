@@ -488,9 +488,9 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         if (stats && !c->body_counts) { int rc = dev_alloc(c, &c->body_counts, (size_t)std::max<int64_t>(c->cfg.capacity, 1)); if (rc) return rc; }
         for (int64_t plo = lo; plo < hi; plo += pass) {
             const int64_t phi = std::min(hi, plo + pass);
-            double *pp = partial ? partial + 4 * ((plo - lo) / kBlock) : nullptr;
+            double *pp = partial ? partial + 4 * ((plo - lo) / kF64Block) : nullptr;
             auto args = [&](auto kern) {
-                hipLaunchKernelGGL(kern, dim3(blocks_for(phi - plo, kBlock)), dim3(kBlock), 0, c->stream, c->gd, c->ld, c->perm,
+                hipLaunchKernelGGL(kern, dim3(blocks_for(phi - plo, kF64Block)), dim3(kF64Block), 0, c->stream, c->gd, c->ld, c->perm,
                                    (double2 *)c->pos, (double2 *)c->vel, (const double *)c->mass,
                                    (double2 *)c->force, plo, phi, c->cfg.theta, c->cfg.G, c->cfg.dt,
                                    integrate ? 1 : 0, c->ctr, pp, stats ? c->body_counts : nullptr);
@@ -498,6 +498,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
             if (c->compat) { if (stats) args(walk_f64_kernel<true, true>); else args(walk_f64_kernel<true, false>); }
             else           { if (stats) args(walk_f64_kernel<false, true>); else args(walk_f64_kernel<false, false>); }
         }
+        per_partial = kF64Block;
         BH_HIP(c, hipGetLastError());
     } else if (c->exact) {
         for (int64_t plo = lo; plo < hi; plo += pass) {

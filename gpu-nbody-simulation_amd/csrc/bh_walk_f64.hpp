@@ -42,8 +42,16 @@ __device__ __forceinline__ double w64_f64(int32_t lo, int32_t hi)
     return __hiloint2double(hi, lo);
 }
 
+// One wavefront per workgroup: a body group's walk takes 0.3x .. 3x the mean, and a workgroup's slot is only
+// re-used when its LAST wave has finished -- with four waves per workgroup the mean occupancy of this kernel was
+// 5.5 of 8 waves per SIMD (SQ_WAVE_CYCLES), with one it is the dispatcher's to fill wave by wave.
+#ifndef BH_F64_BLOCK
+#define BH_F64_BLOCK 64
+#endif
+constexpr int kF64Block = BH_F64_BLOCK;
+
 template <bool COMPAT, bool STATS>
-__global__ __launch_bounds__(kBlock) void walk_f64_kernel(
+__global__ __launch_bounds__(kF64Block) void walk_f64_kernel(
     const NodeD *__restrict__ gd, const LinkD *__restrict__ ld, const uint32_t *__restrict__ perm,
     double2 *__restrict__ pos, double2 *__restrict__ vel, const double *__restrict__ mass,
     double2 *__restrict__ force_out, int64_t lo, int64_t hi, double theta, double G, double dt,
@@ -51,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void walk_f64_kernel(
 {
     if (ctr->overflow) return;
     const int lane = lane_id();
-    const int64_t s = lo + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t s = lo + (int64_t)blockIdx.x * kF64Block + threadIdx.x;
     const bool valid = s < hi;
     const int64_t body = valid ? (int64_t)perm[s] : -1;
     const double2 p = valid ? pos[body] : double2{0.0, 0.0};
@@ -103,41 +111,79 @@ __global__ __launch_bounds__(kBlock) void walk_f64_kernel(
         }
     };
 
-    // one node for the lanes in `mask` (all arguments wave-uniform)
+    // one node for the lanes in `mask` (all arguments wave-uniform).  The kernel is vector-issue bound (every fp64
+    // instruction costs 5.3 cycles per wave, v_rsq_f64 17: scripts/calib/f64_issue_calib.hip), so the per-node work is
+    // written out instruction by instruction and everything wave-uniform stays on the scalar side: the empty-node
+    // and leaf tests are integer tests on SGPRs, the lane sets are 64-bit masks straight from v_cmp (no per-lane
+    // booleans), and the force is accumulated under EXEC = the accepting lanes instead of through selects.
+    const int32_t body32 = (int32_t)body;                         // (perm is 32-bit; -1 on padding lanes)
+    const int32_t compat32 = -body32 - 2;                         // occ + 2 == -body, project.cu:646
+    const double c0375 = 0.375, tiny = 1e-15, ntiny = -1e-15;
     auto eval = [&](double cx, double cy, double m, double size, int32_t child, int32_t occ, uint64_t mask) {
-        if (m <= 1e-15) return;                                   // project.cu:617
-        const bool mine = (mask >> lane) & 1ull;
+        // m <= 1e-15 (project.cu:617) on the bit pattern, with scalar integer compares: for doubles that are not
+        // NaN, a <= b  <=>  the same on their sign-magnitude integers (bits of 1e-15: 0x3CD203AF'9EE75616); a node's
+        // mass is a sum of the bodies' masses or +0.0
+        {
+            const int32_t mh = __double2hiint(m);
+            if (mh <= 0x3CD203AF && (mh < 0x3CD203AF || (uint32_t)__double2loint(m) <= 0x9EE75616u)) return;
+        }
         const bool leaf = child < 0;                              // project.cu:623-626
-        const double dx = cx - p.x, dy = cy - p.y;
-        const double d2 = fma(dx, dx, dy * dy);
+        double dx, dy, d2, y, t, e;
         // y = 1 / sqrt(d2): v_rsq_f64 is good to ~2^-26; with e = 1 - d2 y0^2 (|e| <~ 3e-8), 1 / sqrt(1 - e) =
         // 1 + e/2 + 3 e^2 / 8 + O(e^3) -- ONE third-order step reaches fp64 rounding (the neglected term is
-        // 5 e^3 / 16 ~ 1e-23), five instructions instead of the eight of two Newton steps
-#if defined(BH_F64_RSQ32) && BH_F64_RSQ32
-        const double y0 = (double)__builtin_amdgcn_rsqf((float)d2);     // A/B: fp32 seed (2^-23) -- the same step still reaches 1e-20
-#else
-        const double y0 = __builtin_amdgcn_rsq(d2);
-#endif
-        const double e = fma(-(d2 * y0), y0, 1.0);
-        const double y = fma(y0, e * fma(0.375, e, 0.5), y0);
-        const double d = fma(d2, y, 1e-15);                       // sqrt(d2) + 1e-15, project.cu:634
-        const bool accept = leaf || (size < theta * d);           // size / d < theta, project.cu:643
-        bool self = false;
+        // 5 e^3 / 16 ~ 1e-23), five instructions instead of the eight of two Newton steps.  (An fp32 seed,
+        // v_cvt + v_rsq_f32 + v_cvt, costs the same 17 cycles as v_rsq_f64: measured, no gain.)
+        asm volatile(
+            "v_add_f64 %[dx], %[cx], -%[px]\n\t"
+            "v_add_f64 %[dy], %[cy], -%[py]\n\t"
+            "v_mul_f64 %[d2], %[dy], %[dy]\n\t"
+            "v_fma_f64 %[d2], %[dx], %[dx], %[d2]\n\t"
+            "v_rsq_f64 %[y], %[d2]\n\t"
+            "s_nop 0\n\t"                                          // gfx94x/95x: one wait state between a TRANS result and its use
+            "v_mul_f64 %[t], %[d2], -%[y]\n\t"
+            "v_fma_f64 %[e], %[t], %[y], 1.0\n\t"
+            "v_fma_f64 %[t], %[e], %[k], 0.5\n\t"
+            "v_mul_f64 %[e], %[e], %[t]\n\t"
+            "v_fma_f64 %[y], %[y], %[e], %[y]"
+            : [dx] "=&v"(dx), [dy] "=&v"(dy), [d2] "=&v"(d2), [y] "=&v"(y), [t] "=&v"(t), [e] "=&v"(e)
+            : [cx] "s"(cx), [cy] "s"(cy), [px] "v"(p.x), [py] "v"(p.y), [k] "s"(c0375));
+        uint64_t takem, open;
         if (leaf) {
-            self = ((int64_t)occ == body);
-            if (COMPAT) self = self || ((int64_t)occ + 2 == -body);   // project.cu:646
+            uint64_t self = __builtin_amdgcn_ballot_w64(occ == body32);
+            if (COMPAT) self |= __builtin_amdgcn_ballot_w64(occ == compat32);
+            takem = mask & ~self;
+            open = 0;
+        } else {
+            // d = sqrt(d2) + 1e-15 (project.cu:634) as d2 * y + 1e-15; size / d < theta (project.cu:643) as size < theta * d
+            uint64_t acc;
+            asm volatile(
+                "v_fma_f64 %[t], %[d2], %[y], %[tiny]\n\t"
+                "v_mul_f64 %[t], %[theta], %[t]\n\t"
+                "v_cmp_lt_f64_e64 %[acc], %[size], %[t]"
+                : [t] "=&v"(t), [acc] "=s"(acc)
+                : [d2] "v"(d2), [y] "v"(y), [tiny] "v"(tiny), [theta] "s"(theta), [size] "s"(size));
+            takem = mask & acc;
+            open = mask & ~acc;
         }
-        const bool take = mine && accept && !self;
-        const uint64_t takem = __ballot(take);
-        if (takem != 0) {                                         // (a cell every lane opens: nine fp64 instructions saved)
-            // M / (d2 * d):  1 / d2 = y * y,  1 / d = 1 / (sqrt(d2) + 1e-15) = y * (1 - 1e-15 * y) to second order
-            const double inv_d = fma(-1e-15 * y, y, y);
-            const double wgt = take ? m * (y * y) * inv_d : 0.0;
-            sx = fma(wgt, dx, sx);
-            sy = fma(wgt, dy, sy);
+        if (takem != 0) {                                         // (a cell every lane opens: seven fp64 instructions saved)
+            // M / (d2 * d):  1 / d2 = y * y,  1 / d = 1 / (sqrt(d2) + 1e-15) = y * (1 - 1e-15 * y) to second order;
+            // added for the accepting lanes only (the others may hold inf / NaN here: a body's own leaf has d2 = 0)
+            uint64_t saved;
+            asm volatile(
+                "v_mul_f64 %[t], %[y], %[ntiny]\n\t"
+                "v_mul_f64 %[e], %[y], %[y]\n\t"
+                "v_fma_f64 %[t], %[t], %[y], %[y]\n\t"
+                "v_mul_f64 %[e], %[e], %[m]\n\t"
+                "v_mul_f64 %[t], %[e], %[t]\n\t"
+                "s_and_saveexec_b64 %[saved], %[takem]\n\t"
+                "v_fma_f64 %[sx], %[t], %[dx], %[sx]\n\t"
+                "v_fma_f64 %[sy], %[t], %[dy], %[sy]\n\t"
+                "s_mov_b64 exec, %[saved]"
+                : [t] "=&v"(t), [e] "=&v"(e), [sx] "+v"(sx), [sy] "+v"(sy), [saved] "=&s"(saved)
+                : [y] "v"(y), [ntiny] "s"(ntiny), [m] "s"(m), [takem] "s"(takem), [dx] "v"(dx), [dy] "v"(dy)
+                : "scc");
         }
-        const uint64_t open = leaf ? 0ull : __ballot(mine && !accept);
-        if (STATS) { n_vis += __popcll(mask); ++n_wave; n_int += __popcll(takem); my_int += take ? 1u : 0u; }
+        if (STATS) { n_vis += __popcll(mask); ++n_wave; n_int += __popcll(takem); my_int += (uint32_t)((takem >> lane) & 1ull); }
         if (open != 0) {
             if (h_free) { h_idx = child; h_mask = open; h_free = false; }
             else push(child, open);
@@ -193,7 +239,18 @@ __global__ __launch_bounds__(kBlock) void walk_f64_kernel(
         }
         if (STATS && body_counts) body_counts[body] = my_int;
     }
-    if (partial) block_bounds_to_partial(valid, np.x, np.y, partial + 4 * (size_t)blockIdx.x);
+    if (partial) {                                                // min/max of the new positions per workgroup (next root box)
+        if (kF64Block == kWave) {
+            const double xlo = wave_min(valid ? np.x : (double)INFINITY), xhi = wave_max(valid ? np.x : -(double)INFINITY);
+            const double ylo = wave_min(valid ? np.y : (double)INFINITY), yhi = wave_max(valid ? np.y : -(double)INFINITY);
+            if (lane == 0) {
+                double *o = partial + 4 * (size_t)blockIdx.x;
+                o[0] = xlo; o[1] = xhi; o[2] = ylo; o[3] = yhi;
+            }
+        } else {
+            block_bounds_to_partial(valid, np.x, np.y, partial + 4 * (size_t)blockIdx.x);
+        }
+    }
     if (STATS && lane == 0) {
         atomicAdd(&ctr->visits, n_vis);
         atomicAdd(&ctr->interactions, n_int);
