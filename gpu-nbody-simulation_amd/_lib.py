@@ -50,6 +50,7 @@ class bh_stats_t(C.Structure):
         ("build_bytes", C.c_uint64), ("walk_bytes", C.c_uint64), ("wave_quads", C.c_uint64),
         ("sort_spill_buckets", C.c_uint64),
         ("let_tree_ms", C.c_double), ("let_pack_ms", C.c_double),
+        ("sort_rerun_buckets", C.c_uint64),
     ]
 
 

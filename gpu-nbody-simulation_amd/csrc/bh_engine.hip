@@ -320,11 +320,12 @@ int enqueue_build_t(bh_ctx *c)
                                    0, (int)nbl, c->splitters, c->sort_dig);
                 hipLaunchKernelGGL(radix_rowscan, dim3(1 << NBITS), dim3(kBlock), 0, st, c->radix_counts, c->bsum_sort, (int)nbl);
                 hipLaunchKernelGGL((radix_scatter_w<SI, NBITS, 1, true>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->vals[0],
-                                   c->keys[1], c->vals[1], c->radix_counts, c->bsum_sort, n, 0, (int)nbl, c->sort_dig);
+                                   c->keys[1], c->vals[1], c->radix_counts, c->bsum_sort, n, 0, (int)nbl, c->sort_dig,
+                                   c->bsum_sort + kBucketStartOffset);
             };
             if (nb == kBuckets) pass(std::integral_constant<int, 8>{}); else pass(std::integral_constant<int, 10>{});
             hipLaunchKernelGGL(bucket_sort_kernel, dim3(nb), dim3(kBsThreads), 0, st, c->keys[1], c->keys[0], c->vals[0],
-                               c->bsum_sort, nb, &c->ctr->sort_spills);
+                               c->bsum_sort, c->bsum_sort + kBucketStartOffset, &c->ctr->sort_spills, &c->ctr->sort_reruns);
             cur = 0;
         } else if (c->sort_wave_rank) {
             // default: kSortBits-wide digits, wave-private ranking, digit-sorted write-out
@@ -691,7 +692,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
       // sized for kSortTile only, the 512-key tiles of that override wrote past the end between 1M and 4M bodies)
       const size_t big = (!c->exact && cap > kBucketMaxN) ? (size_t)kBucketsBig * blocks_for(std::min<int64_t>(cap, kBucketMaxNBig), kBlock * kSmallItems) : 0;
       A(&c->radix_counts, std::max<size_t>((size_t)(1 << kSortBits) * nbl, big));
-      A(&c->bsum_sort, kBucketsBig + 8);
+      A(&c->bsum_sort, 2 * kBucketStartOffset);               // bucket totals, then bucket starts
       A(&c->splitters, kBucketsBig);
       if (!c->exact) A(&c->sort_dig, (size_t)std::min<int64_t>(cap, kBucketMaxNBig) + 16);
 #ifdef BHGPU_EXPERIMENTS
@@ -1161,6 +1162,7 @@ int bh_stats(bh_ctx *c, bh_stats_t *out)
         TreeCounters h{};
         BH_HIP(c, hipMemcpy(&h, c->ctr, sizeof(h), hipMemcpyDeviceToHost));
         out->sort_spill_buckets = h.sort_spills;
+        out->sort_rerun_buckets = h.sort_reruns;
     }
     if (c->tree_valid) {
         TreeCounters h{};

@@ -39,7 +39,7 @@ struct TreeCounters {
     uint32_t n_internal;       // I  (written by the scan)
     uint32_t overflow;         // 1 if I > internal capacity
     uint32_t sort_spills;      // buckets of the bucket sort that did not fit LDS (cumulative; bh_sort.hpp)
-    uint32_t pad;
+    uint32_t sort_reruns;      // buckets whose three top-byte passes met a long run of equal top bits and were sorted again in full
     unsigned long long visits, interactions;
     unsigned long long wave_nodes;   // nodes evaluated by wavefronts (one count per wave per node)
     unsigned long long wave_quads;   // sibling quads loaded by wavefronts (one count per wave per quad)

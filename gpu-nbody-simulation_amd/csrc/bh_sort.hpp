@@ -74,6 +74,7 @@ constexpr int kSortBits = 8;
 // 256 buckets up to 1M bodies, 1,024 up to 4M (BITS = 8 / 10 in the counting pass): the average bucket stays
 // at most a third of what one workgroup sorts in LDS.
 constexpr int kBuckets = 256, kBucketsBig = 1024;
+constexpr int kBucketStartOffset = kBucketsBig + 8;        // bsum_sort: [0, nb) bucket totals, [kBucketStartOffset, +nb) bucket starts
 constexpr int kDigits = 256;                              // the in-LDS sort's own 8-bit digits
 constexpr int kMaxSplitSamples = 2048;                    // sample positions sorted by keys_kernel's splitter workgroup
 constexpr uint64_t kKeyMask40 = (1ull << 40) - 1;
@@ -171,7 +172,8 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
                                                            const uint32_t *__restrict__ offs,
                                                            const uint32_t *__restrict__ row_total, int64_t n,
                                                            int shift, int nblocks,
-                                                           const uint16_t *__restrict__ dig16 = nullptr)
+                                                           const uint16_t *__restrict__ dig16 = nullptr,
+                                                           uint32_t *__restrict__ bucket_start = nullptr)
 {
     static_assert(!BUCKET || PACK == 1, "the bucket pass moves packed keys");
     // (4) the tile is first sorted by digit INTO LDS, then written out in that order: the keys a digit
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
         for (int j = 0; j < DPT; ++j) {
             const int d = DPT * t + j;
             gdelta[d] = (int32_t)(digit_base + offs[(int64_t)d * nblocks + blockIdx.x]) - (int32_t)lstart;
+            if (BUCKET && blockIdx.x == 0) bucket_start[d] = digit_base;   // where bucket d begins: bucket_sort_kernel reads it
             uint32_t run = lstart;
 #pragma unroll
             for (int k = 0; k < kWavesPerBlock; ++k) { const uint32_t c = woff[k][d]; woff[k][d] = run; run += c; }
@@ -322,41 +325,61 @@ __device__ __forceinline__ uint32_t bs_scan256(uint32_t v, uint32_t *sm, uint32_
     return base + inc - v;
 }
 
-// m <= 1,024 * ITEMS keys of one bucket: stable LSD passes over the key bytes that differ inside the bucket,
-// keys in registers between passes (wave w owns the contiguous keys [w * 64 * ITEMS, ...) as in
-// radix_scatter_w), ranks by ballot matching over the bits of the byte that differ, one LDS buffer.
+// m <= 1,024 * ITEMS keys of one bucket: stable LSD byte passes, keys in registers between passes (wave w owns the
+// contiguous keys [w * 64 * ITEMS, ...) as in radix_scatter_w), one LDS buffer.
 // Who shares my digit?  Matching by ballots costs ~8 vector instructions per digit bit and the kernel was bound
 // by exactly those (8.4 M vector instructions per launch at N = 1M, 2,050 per wave).  Instead every wave
 // owns a 256-entry table of 64-bit lane masks in LDS: a lane ORs its lane bit into the entry of its digit, reads
 // the entry back -- the mask of its peers -- and clears it (LDS instructions of one wave execute in order).
+//
+// How many passes?  A workgroup's time is its chain of passes (barriers, the 256-digit scan, the trip through LDS:
+// ~4.5 us each, whatever the number of keys -- profiles/r03_final/build_ab.txt), one workgroup per CU, and the kernel
+// is as slow as its slowest bucket: the keys of a core bucket of a Plummer sphere span 2^26, those of a halo bucket
+// 2^38 -- four passes against five.  So the keys are taken relative to the bucket's smallest (the SPAN counts, not
+// the differing bit positions: a bucket astride a quadrant boundary differs in bit 39), and a bucket whose span
+// exceeds 24 bits is sorted by the TOP 24 bits of its span in three passes, after which every run of keys equal in
+// those bits -- almost always a single key: <= 12,288 keys over 2^24 values -- is put in order by counting inside
+// the run.  A run longer than kFixRun (keys piled up on a few values below a wide span) sends the workgroup through
+// the full passes instead.  Either way the result is the stable order by key.
+constexpr int kFixRun = 8;
 template <int ITEMS>
 __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in, int m, uint64_t *skey,
                                                 uint32_t (*woff)[kDigits], uint64_t (*match)[kDigits],
-                                                uint32_t *sm, uint64_t *s_or,
-                                                uint64_t *__restrict__ kout, uint32_t *__restrict__ vout)
+                                                uint32_t *sm, uint64_t *s_red, uint32_t *s_flag,
+                                                uint64_t *__restrict__ kout, uint32_t *__restrict__ vout,
+                                                uint32_t *__restrict__ reruns)
 {
     const int t = threadIdx.x, w = wave_id(), l = lane_id();
     const int wbase = w * (kWave * ITEMS);
     uint64_t key[ITEMS];
-    const uint64_t k0 = in[0];
-    uint64_t x = 0;
+    uint64_t kmin = ~0ull, kmax = 0ull;
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const int i = wbase + r * kWave + l;
         key[r] = (i < m) ? in[i] : ~0ull;
-        x |= (i < m) ? (key[r] ^ k0) & kKeyMask40 : 0ull;
+        if (i < m) {
+            const uint64_t k = key[r] & kKeyMask40;
+            kmin = (k < kmin) ? k : kmin; kmax = (k > kmax) ? k : kmax;
+        }
     }
     for (int k = t; k < kBsWaves * kDigits; k += kBsThreads) { (&woff[0][0])[k] = 0; (&match[0][0])[k] = 0ull; }
-    // which key bits differ inside the bucket: only those bytes need a pass
+    if (t == 0) *s_flag = 0u;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) x |= __shfl_xor(x, o);
-    if (l == 0) s_or[w] = x;
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint64_t a = __shfl_xor(kmin, o), b = __shfl_xor(kmax, o);
+        kmin = (a < kmin) ? a : kmin; kmax = (b > kmax) ? b : kmax;
+    }
+    if (l == 0) { s_red[w] = kmin; s_red[kBsWaves + w] = kmax; }
     __syncthreads();
-    x = 0;
+    kmin = ~0ull; kmax = 0ull;
 #pragma unroll
-    for (int k = 0; k < kBsWaves; ++k) x |= s_or[k];
-    const int passes = x ? (64 - __clzll(x) + 7) / 8 : 0;
-    if (passes == 0) {                                          // all keys equal (or one key): order is final
+    for (int k = 0; k < kBsWaves; ++k) {
+        const uint64_t a = s_red[k], b = s_red[kBsWaves + k];
+        kmin = (a < kmin) ? a : kmin; kmax = (b > kmax) ? b : kmax;
+    }
+    const uint64_t span = kmax - kmin;
+    const int bits = span ? 64 - __clzll(span) : 0;
+    if (bits == 0) {                                            // all keys equal (or one key): order is final
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const int i = wbase + r * kWave + l;
@@ -364,67 +387,129 @@ __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in,
         }
         return;
     }
-    for (int p = 0; p < passes; ++p) {
-        const int shift = 8 * p;
-        // peers, ranks and counts first (kept in registers), wave totals per digit by the first peer
-        uint32_t rank[ITEMS], cnt[ITEMS];
+    // keys relative to the smallest (the body index in bits 40.. is untouched: no borrow, key >= kmin)
 #pragma unroll
-        for (int r = 0; r < ITEMS; ++r) {
-            const int i = wbase + r * kWave + l;
-            const bool valid = i < m;
-            const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
-            uint64_t peers = 0;
-            if (valid) (void)__hip_atomic_fetch_or(&match[w][d], 1ull << l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __builtin_amdgcn_wave_barrier();
-            if (valid) peers = match[w][d];
-            __builtin_amdgcn_wave_barrier();
-            if (valid) match[w][d] = 0ull;
-            __builtin_amdgcn_wave_barrier();
-            rank[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
-            cnt[r] = (uint32_t)__popcll(peers);
-            if (valid && rank[r] == 0) woff[w][d] += cnt[r];    // one lane per digit; this wave's row only
-        }
-        __syncthreads();
-        {
-            uint32_t c = 0;
-            if (t < kDigits) {
-#pragma unroll
-                for (int k = 0; k < kBsWaves; ++k) c += woff[k][t];
-            }
-            uint32_t all;
-            uint32_t run = bs_scan256(c, sm, all);
-            if (t < kDigits) {
-#pragma unroll
-                for (int k = 0; k < kBsWaves; ++k) { const uint32_t cc = woff[k][t]; woff[k][t] = run; run += cc; }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < ITEMS; ++r) {
-            const int i = wbase + r * kWave + l;
-            const bool valid = i < m;
-            const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
-            uint32_t o = 0;
-            if (valid) o = woff[w][d];                          // every peer reads the same word ...
-            __builtin_amdgcn_wave_barrier();
-            if (valid) skey[o + rank[r]] = key[r];
-            if (valid && rank[r] == 0) woff[w][d] = o + cnt[r]; // ... before the first peer advances it
-            __builtin_amdgcn_wave_barrier();
-        }
-        __syncthreads();
-        if (p + 1 < passes) {
+    for (int r = 0; r < ITEMS; ++r) key[r] -= (wbase + r * kWave + l < m) ? kmin : 0ull;
+    const int full = (bits + 7) / 8;
+    int first = 0, passes = full;
+    bool fix = false;
+    // (two top passes and runs of up to 16 keys: 20.1 against 20.8 us at N = 1M, and twice the keys per run -- not taken)
+    if (full > 3) { first = bits - 24; passes = 3; fix = true; }
+    for (;;) {
+        for (int p = 0; p < passes; ++p) {
+            const int shift = first + 8 * p;
+            // peers, ranks and counts first (kept in registers), wave totals per digit by the first peer
+            uint32_t rank[ITEMS], cnt[ITEMS];
 #pragma unroll
             for (int r = 0; r < ITEMS; ++r) {
                 const int i = wbase + r * kWave + l;
-                key[r] = (i < m) ? skey[i] : ~0ull;
+                const bool valid = i < m;
+                const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+                uint64_t peers = 0;
+                if (valid) (void)__hip_atomic_fetch_or(&match[w][d], 1ull << l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_wave_barrier();
+                if (valid) peers = match[w][d];
+                __builtin_amdgcn_wave_barrier();
+                if (valid) match[w][d] = 0ull;
+                __builtin_amdgcn_wave_barrier();
+                rank[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+                cnt[r] = (uint32_t)__popcll(peers);
+                if (valid && rank[r] == 0) woff[w][d] += cnt[r];    // one lane per digit; this wave's row only
             }
-            for (int k = t; k < kBsWaves * kDigits; k += kBsThreads) (&woff[0][0])[k] = 0;
             __syncthreads();
+            {
+                uint32_t c = 0;
+                if (t < kDigits) {
+#pragma unroll
+                    for (int k = 0; k < kBsWaves; ++k) c += woff[k][t];
+                }
+                uint32_t all;
+                uint32_t run = bs_scan256(c, sm, all);
+                if (t < kDigits) {
+#pragma unroll
+                    for (int k = 0; k < kBsWaves; ++k) { const uint32_t cc = woff[k][t]; woff[k][t] = run; run += cc; }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) {
+                const int i = wbase + r * kWave + l;
+                const bool valid = i < m;
+                const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+                uint32_t o = 0;
+                if (valid) o = woff[w][d];                          // every peer reads the same word ...
+                __builtin_amdgcn_wave_barrier();
+                if (valid) skey[o + rank[r]] = key[r];
+                if (valid && rank[r] == 0) woff[w][d] = o + cnt[r]; // ... before the first peer advances it
+                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();
+            if (p + 1 < passes) {
+#pragma unroll
+                for (int r = 0; r < ITEMS; ++r) {
+                    const int i = wbase + r * kWave + l;
+                    key[r] = (i < m) ? skey[i] : ~0ull;
+                }
+                for (int k = t; k < kBsWaves * kDigits; k += kBsThreads) (&woff[0][0])[k] = 0;
+                __syncthreads();
+            }
         }
+        if (!fix) break;
+        // ---- the keys are in order of their top 24 span bits, equal ones in input order: finish every run of equal
+        // top bits by counting.  Position = own position + (later keys of the run that are smaller) - (earlier keys of
+        // the run that are larger); keys equal in all bits keep their order.
+        const uint64_t lowmask = (1ull << first) - 1ull;
+        uint32_t npos[ITEMS];
+        bool too_long = false;
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const int i = t + r * kBsThreads;
+            npos[r] = (uint32_t)i;
+            if (i < m) {
+                const uint64_t kk = skey[i] & kKeyMask40;
+                const uint64_t top = kk >> first, low = kk & lowmask;
+                int delta = 0, j;
+                for (j = i - 1; j >= 0 && i - j <= kFixRun; --j) {
+                    const uint64_t q = skey[j] & kKeyMask40;
+                    if ((q >> first) != top) break;
+                    delta -= ((q & lowmask) > low) ? 1 : 0;
+                }
+                too_long = too_long || (j >= 0 && i - j > kFixRun);
+                for (j = i + 1; j < m && j - i <= kFixRun; ++j) {
+                    const uint64_t q = skey[j] & kKeyMask40;
+                    if ((q >> first) != top) break;
+                    delta += ((q & lowmask) < low) ? 1 : 0;
+                }
+                too_long = too_long || (j < m && j - i > kFixRun);
+                key[r] = skey[i];
+                npos[r] = (uint32_t)(i + delta);
+            }
+        }
+        if (too_long) *s_flag = 1u;
+        __syncthreads();
+        if (*s_flag == 0u) {                                        // straight to memory, at most kFixRun places from a coalesced store
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r)
+                if (t + r * kBsThreads < m) {
+                    kout[npos[r]] = (key[r] & kKeyMask40) + kmin;
+                    vout[npos[r]] = (uint32_t)(key[r] >> kPackShift);
+                }
+            return;
+        }
+        // a long run: the full passes from the input (rare: bodies piled up on a few key values under a wide span)
+        if (t == 0) atomicAdd(reruns, 1u);
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const int i = wbase + r * kWave + l;
+            key[r] = (i < m) ? in[i] - kmin : ~0ull;
+        }
+        for (int k = t; k < kBsWaves * kDigits; k += kBsThreads) (&woff[0][0])[k] = 0;
+        __syncthreads();
+        first = 0; passes = full; fix = false;
     }
     for (int i = t; i < m; i += kBsThreads) {
         const uint64_t k = skey[i];
-        kout[i] = k & kKeyMask40;
+        kout[i] = (k & kKeyMask40) + kmin;
         vout[i] = (uint32_t)(k >> kPackShift);
     }
 }
@@ -435,42 +520,33 @@ __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in,
 __global__ __launch_bounds__(kBsThreads) void bucket_sort_kernel(uint64_t *__restrict__ bucketed,
                                                                   uint64_t *__restrict__ kout,
                                                                   uint32_t *__restrict__ vout,
-                                                                  const uint32_t *__restrict__ bucket_total, int nb,
-                                                                  uint32_t *__restrict__ spills)
+                                                                  const uint32_t *__restrict__ bucket_total,
+                                                                  const uint32_t *__restrict__ bucket_start,
+                                                                  uint32_t *__restrict__ spills,
+                                                                  uint32_t *__restrict__ reruns)
 {
     __shared__ uint64_t skey[kBucketCap];
     __shared__ uint32_t woff[kBsWaves][kDigits];
     __shared__ uint64_t match[kBsWaves][kDigits];
     __shared__ uint32_t sm[8];
-    __shared__ uint64_t s_or[kBsWaves];
-    __shared__ uint32_t s_start, s_m;
+    __shared__ uint64_t s_or[2 * kBsWaves];
+    __shared__ uint32_t s_flag;
     const int t = threadIdx.x, w = wave_id(), l = lane_id();
-    {
-        // where this bucket starts: exclusive scan of the nb <= 1,024 bucket totals, one per thread
-        const uint32_t mine = (t < nb) ? bucket_total[t] : 0u;
-        const uint32_t inc = wave_inclusive_sum(mine);
-        __shared__ uint32_t s_wtot[kBsWaves];
-        if (l == kWave - 1) s_wtot[w] = inc;
-        __syncthreads();
-        uint32_t base = 0;
-#pragma unroll
-        for (int k = 0; k < kBsWaves; ++k) base += (k < w) ? s_wtot[k] : 0u;
-        if (t == (int)blockIdx.x) { s_start = base + inc - mine; s_m = mine; }
-        __syncthreads();
-    }
-    const int64_t start = s_start;
-    const int m = (int)s_m;
+    // where this bucket starts and how many keys it holds: the counting pass's scatter left both (wave-uniform loads)
+    const int64_t start = bucket_start[blockIdx.x];
+    const int m = (int)bucket_total[blockIdx.x];
     if (m == 0) return;
     uint64_t *in = bucketed + start;
     uint64_t *ko = kout + start;
     uint32_t *vo = vout + start;
 
-    if (m <= 1 * kBsThreads) { bucket_sort_lds<1>(in, m, skey, woff, match, sm, s_or, ko, vo); return; }
-    if (m <= 2 * kBsThreads) { bucket_sort_lds<2>(in, m, skey, woff, match, sm, s_or, ko, vo); return; }
-    if (m <= 4 * kBsThreads) { bucket_sort_lds<4>(in, m, skey, woff, match, sm, s_or, ko, vo); return; }
-    if (m <= 6 * kBsThreads) { bucket_sort_lds<6>(in, m, skey, woff, match, sm, s_or, ko, vo); return; }
-    if (m <= 8 * kBsThreads) { bucket_sort_lds<8>(in, m, skey, woff, match, sm, s_or, ko, vo); return; }
-    if (m <= kBucketCap) { bucket_sort_lds<kBucketItemsMax>(in, m, skey, woff, match, sm, s_or, ko, vo); return; }
+    if (m <= 1 * kBsThreads) { bucket_sort_lds<1>(in, m, skey, woff, match, sm, s_or, &s_flag, ko, vo, reruns); return; }
+    if (m <= 2 * kBsThreads) { bucket_sort_lds<2>(in, m, skey, woff, match, sm, s_or, &s_flag, ko, vo, reruns); return; }
+    if (m <= 4 * kBsThreads) { bucket_sort_lds<4>(in, m, skey, woff, match, sm, s_or, &s_flag, ko, vo, reruns); return; }
+    if (m <= 5 * kBsThreads) { bucket_sort_lds<5>(in, m, skey, woff, match, sm, s_or, &s_flag, ko, vo, reruns); return; }
+    if (m <= 6 * kBsThreads) { bucket_sort_lds<6>(in, m, skey, woff, match, sm, s_or, &s_flag, ko, vo, reruns); return; }
+    if (m <= 8 * kBsThreads) { bucket_sort_lds<8>(in, m, skey, woff, match, sm, s_or, &s_flag, ko, vo, reruns); return; }
+    if (m <= kBucketCap) { bucket_sort_lds<kBucketItemsMax>(in, m, skey, woff, match, sm, s_or, &s_flag, ko, vo, reruns); return; }
 
     // which key bits differ inside the bucket: only those bytes need a pass
     const uint64_t k0 = in[0];

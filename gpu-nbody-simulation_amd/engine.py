@@ -75,6 +75,7 @@ class BhStats:
     sort_spill_buckets: int = 0  # bucket-sort buckets sorted through memory since creation (0 in steady motion)
     let_tree_ms: float = 0.0    # last let_build: global box + local tree
     let_pack_ms: float = 0.0    # last let_build: LET marking / numbering / packing
+    sort_rerun_buckets: int = 0  # bucket-sort buckets whose short sort met a long run and was repeated in full (bh_sort.hpp)
 
 
 def _dptr(a: np.ndarray):
@@ -202,7 +203,7 @@ class BarnesHutEngine:
         return BhStats(s.n_bodies, s.n_nodes, s.n_internal, s.steps_done, s.visits, s.interactions,
                        s.wave_nodes, s.last_step_ms, s.build_ms, s.walk_ms, s.device_bytes, s.keys_ms, s.sort_ms,
                        s.scan_ms, s.nodes_ms, s.build_bytes, s.walk_bytes, s.wave_quads, s.sort_spill_buckets,
-                       s.let_tree_ms, s.let_pack_ms)
+                       s.let_tree_ms, s.let_pack_ms, s.sort_rerun_buckets)
 
     def step_times(self):
         """(step_ms[k], walk_ms[k]) of the steps of the last step() call (at most 4,096): HIP events per step."""

@@ -146,6 +146,9 @@ typedef struct bh_stats_t {
     /* the last bh_let_build (distributed step), HIP events on the context's stream (ABI 3)  */
     double   let_tree_ms;        /* global box + the local tree under it                     */
     double   let_pack_ms;        /* marking, numbering and packing the peers' LETs           */
+    uint64_t sort_rerun_buckets; /* buckets of the bucket sort whose short sort (the top 24 bits of the keys' span, then
+                                    runs of equal top bits by counting) met a run of more than 8 keys and was repeated
+                                    with all byte passes, since bh_create (0 unless bodies pile up)          */
 } bh_stats_t;
 
 typedef struct bh_ctx bh_ctx;

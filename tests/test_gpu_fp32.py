@@ -254,6 +254,38 @@ def test_bucket_sort_with_useless_splitters_spills_and_stays_correct(monkeypatch
         assert np.array_equal(x, y)
 
 
+def test_bucket_sort_reruns_a_bucket_whose_keys_crowd_below_a_wide_span(monkeypatch):
+    """A bucket whose keys span more than 24 bits is sorted by the top 24 bits of that span in three byte passes and
+    finished by counting inside every run of equal top bits (csrc/bh_sort.hpp) -- runs are single keys unless bodies
+    crowd: here 48 bodies sit within a few depth-20 cells of a uniform box, a run of 48 keys that differ in their
+    lowest bits only.  Its workgroup notices (runs are followed for 8 keys), sorts the bucket again with all byte
+    passes and counts that (bh_stats.sort_rerun_buckets); the order is the LSD sort's bit for bit either way, and a
+    box without the crowd reruns nothing."""
+    n = 20000
+    rng = np.random.default_rng(21)
+    base = f32(rng.uniform(-1, 1, (n, 2)))
+    crowd = base.copy()
+    crowd[:48] = f32(np.array([0.3712, -0.2288]) + rng.uniform(0, 1.4e-5, (48, 2)))
+    m, v = f32(rng.uniform(0.5, 1.5, n)), f32(rng.normal(0, 1e-7, (n, 2)))
+    for p, want_rerun in ((crowd, True), (base, False)):
+        res, reruns = [], []
+        for mode in ("1", "0"):
+            monkeypatch.setenv("BH_SORT_BUCKET", mode)
+            with engine(n, max_depth=21, reference_compat=False) as e:
+                e.upload(p, v, m)
+                e.step(3)
+                e.build_tree()
+                nodes, depth = e.export_tree()
+                e.step(3)
+                res.append((nodes, depth) + e.download())
+                st = e.stats()
+                reruns.append(st.sort_rerun_buckets)
+                assert st.sort_spill_buckets == 0
+        for x, y in zip(res[0], res[1]):
+            assert np.array_equal(x, y)
+        assert reruns[1] == 0 and (reruns[0] >= 1) == want_rerun, reruns
+
+
 def test_bucket_sort_with_bodies_piled_into_one_cell(monkeypatch):
     """Bodies that collapse into a few depth-cap cells (what close encounters without softening do to the
     reference's runs: the root box blows up) share their keys.  A key value frequent enough to be sampled
