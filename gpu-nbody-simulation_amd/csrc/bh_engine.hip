@@ -60,6 +60,9 @@ struct bh_ctx {
     int build_items = 0;           // 0 = automatic, else keys per thread in the sort / scan kernels (2, 4, 8)
     bool hilbert = false;                // fp32 mode: Hilbert-ordered keys (BH_HILBERT=0 disables, A/B)
     int partial_count = 0;         // > 0: partial[] holds per-workgroup min/max of the current positions
+    double *bslots = nullptr;      // kBoundSlots running bounds records (bh_bounds.hpp)
+    bool slots_valid = false;      // the last full-range fp32 walk folded the bounds of the current positions into bslots
+    bool slots_dirty = true;       // bslots may hold something else than +-inf (written, not yet consumed by keys_kernel)
 
     // state (double2/double or float2/float).  Exact mode: caller order.  fp32 / mixed: DEVICE order --
     // every reorder_every-th build the bodies are physically permuted into that build's sorted order
@@ -253,14 +256,18 @@ int enqueue_build_t(bh_ctx *c)
 
     // 1. root box (ComputeRootBounds, project.cu:536-573); the per-workgroup partials usually
     //    come from the previous step's walk epilogue
-    if (!c->external_box) {
+    const bool from_slots = !c->external_box && c->slots_valid && n >= 2;
+    double *slots = from_slots ? c->bslots : nullptr;
+    if (from_slots) {
+        c->partial_count = 0; c->slots_valid = false; c->slots_dirty = false;   // (keys_kernel below consumes and resets them)
+    } else if (!c->external_box) {
         if (c->partial_count <= 0) {
             const unsigned nbb = std::max(1u, std::min(1024u, blocks_for(n, kBlock)));
             hipLaunchKernelGGL((bounds_partial<Real2>), dim3(nbb), dim3(kBlock), 0, st, pos, n, c->partial);
             c->partial_count = (int)nbb;
         }
         hipLaunchKernelGGL(bounds_final, dim3(1), dim3(kBlock), 0, st, c->partial, c->partial_count, c->box, c->ctr, Dm);
-        c->partial_count = 0;
+        c->partial_count = 0; c->slots_valid = false;
     }   // else: let_box_kernel has set the global box and cleared the counters
 
     if (n > 0) {
@@ -285,13 +292,13 @@ int enqueue_build_t(bh_ctx *c)
         if (pack)
             hipLaunchKernelGGL((keys_kernel<Real2, true, true>), dim3(blocks_for(n, kBlock) + (bucket ? ns / kWave : 0)), dim3(kBlock),
                                0, st, pos, c->box, c->keys[0], c->vals[0], n, Dm,
-                               bucket ? (const float2 *)c->spos : nullptr, c->splitters, nb, ns);
+                               bucket ? (const float2 *)c->spos : nullptr, c->splitters, nb, ns, slots, c->ctr);
         else if (c->hilbert)
             hipLaunchKernelGGL((keys_kernel<Real2, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
-                               c->box, c->keys[0], c->vals[0], n, Dm);
+                               c->box, c->keys[0], c->vals[0], n, Dm, nullptr, nullptr, 0, 0, slots, c->ctr);
         else
             hipLaunchKernelGGL((keys_kernel<Real2, false>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
-                               c->box, c->keys[0], c->vals[0], n, Dm);
+                               c->box, c->keys[0], c->vals[0], n, Dm, nullptr, nullptr, 0, 0, slots, c->ctr);
         if (c->time_groups) (void)hipEventRecord(c->ev_grp[0], st);
         const unsigned nbl = blocks_for(n, ITEMS == kItems ? kSortTile : TILE);
         int cur = 0;
@@ -394,7 +401,7 @@ int enqueue_build_t(bh_ctx *c)
             const unsigned nbs = blocks_for(n + 1, kBlock * SI);
             hipLaunchKernelGGL((prep_kernel<EXACT, SI, Real2, Real, SReal2, SReal>), dim3(nbs), dim3(kBlock), 0, st,
                                c->keys_sorted, c->perm, pos, mass, c->cnt, c->bsum_u32, (SReal2 *)c->spos,
-                               (SReal *)c->smass, c->terms, c->bsum_d3, c->coarse, n, Dm);
+                               (SReal *)c->smass, c->terms, c->bsum_d3, c->coarse, n, Dm, slots);
             constexpr bool TSRC = !EXACT && std::is_same<Real2, SReal2>::value;   // fp32 state: terms from the sorted copies
             if (nbs <= 8u * kBlock) {
                 // few tiles: every workgroup sums the tile totals before it itself (no scan_top2 launch)
@@ -475,6 +482,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
     owned_range(c, &lo, &hi);
     if (hi <= lo) return BH_OK;
     const bool stats = (c->cfg.flags & BH_FLAG_WALK_STATS) != 0;
+    if (integrate) c->slots_valid = false;                         // (the positions change; the fp32 branch may set it again)
     // a full-range integrating walk also leaves the min/max of the NEW positions per workgroup
     const bool want_partial = integrate && !to_sorted && lo == 0 && hi == c->n;
     double *partial = want_partial ? c->partial : nullptr;
@@ -533,6 +541,15 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         a.group_cost = (lo == 0 && hi == c->n) ? c->group_cost : nullptr;
         a.bucket_consts = c->walk_consts;
         a.body_counts = nullptr;
+        // one launch over all bodies that integrates: the workgroups also fold their bounds into the slot records the
+        // next keys_kernel reduces (bh_bounds.hpp) -- that build then needs no bounds_final launch
+        const bool want_slots = want_partial && pass == hi - lo && part == 0 && !c->let_mode && !c->external_box && c->n >= 2;
+        if (want_slots) {
+            if (c->slots_dirty)
+                hipLaunchKernelGGL(bounds_slots_reset, dim3(1), dim3(kWave), 0, c->stream, c->bslots);
+            a.slots = c->bslots; c->slots_dirty = true;
+        }
+        if (integrate) c->slots_valid = want_slots;
         if (stats) {
             if (!c->body_counts) { int rc = dev_alloc(c, &c->body_counts, (size_t)std::max<int64_t>(c->cfg.capacity, 1)); if (rc) return rc; }
             if (part != 2) BH_HIP(c, hipMemsetAsync(c->body_counts, 0, (size_t)std::max<int64_t>(c->n, 1) * sizeof(uint32_t), c->stream));
@@ -702,7 +719,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
 #endif
     }
     A(&c->bsum_u32, std::max<size_t>(blocks_for(cap + 1, kTile), blocks_for(std::min<int64_t>(cap, 1 << 22) + 1, kBlock * kSmallItems)) + 8);
-    A(&c->partial, 4 * (std::max<size_t>(1024, blocks_for(cap, kWave)) + 2)); A(&c->box, 8);
+    A(&c->partial, 4 * (std::max<size_t>(1024, blocks_for(cap, kWave)) + 2)); A(&c->box, 8); A(&c->bslots, 4 * kBoundSlots);
     A(&c->ctr, 1);
     if (c->exact) {
         A(&c->gd, c->node_cap); A(&c->ld, c->node_cap);
@@ -797,7 +814,7 @@ int bh_upload(bh_ctx *c, const double *pos, const double *vel, const double *mas
     }
     BH_HIP(c, hipMemset(c->force, 0, std::max<int64_t>(n, 1) * 2 * (c->exact ? sizeof(double) : sizeof(float))));
     c->n = n;
-    c->partial_count = 0;
+    c->partial_count = 0; c->slots_valid = false;
     c->samples_n = -1;                                        // new bodies: the next build sorts with the LSD passes
     c->uploaded = true;
     c->tree_valid = false;
@@ -859,7 +876,7 @@ int bh_initialize(bh_ctx *c, int64_t n, uint64_t seed, int32_t kind, double lowe
     }
     BH_HIP(c, hipMemsetAsync(c->force, 0, std::max<int64_t>(n, 1) * 2 * (c->exact ? sizeof(double) : sizeof(float)), c->stream));
     c->n = n;
-    c->partial_count = 0;
+    c->partial_count = 0; c->slots_valid = false;
     c->samples_n = -1;                                        // new bodies: the next build sorts with the LSD passes
     c->uploaded = true;
     c->tree_valid = false;
@@ -1303,7 +1320,7 @@ int bh_scatter_sorted(bh_ctx *c)
                            c->perm, c->sstate, (float2 *)c->pos, (float2 *)c->vel, c->n);
         BH_HIP(c, hipGetLastError());
     }
-    c->partial_count = 0;
+    c->partial_count = 0; c->slots_valid = false;
     c->steps_done += 1;
     return BH_OK;
 }
@@ -1379,7 +1396,7 @@ int bh_let_bounds(bh_ctx *c)
     }
     hipLaunchKernelGGL(let_local_bounds_kernel, dim3(kLetBoxes), dim3(kWave), 0, c->stream, c->partial,
                        c->partial_count, c->lbounds);
-    c->partial_count = 0;
+    c->partial_count = 0; c->slots_valid = false;
     BH_HIP(c, hipGetLastError());
     return BH_OK;
 }
@@ -1614,7 +1631,7 @@ int bh_migrate_unpack(bh_ctx *c, int64_t n_new)
         BH_HIP(c, hipGetLastError());
     }
     c->n = n_new;
-    c->partial_count = 0;
+    c->partial_count = 0; c->slots_valid = false;
     c->samples_n = -1;                                        // new bodies: the next build sorts with the LSD passes
     c->tree_valid = false;
     c->orig_identity = true;                                // arrival order is the caller order from here on

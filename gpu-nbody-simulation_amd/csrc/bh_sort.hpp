@@ -133,12 +133,26 @@ __global__ __launch_bounds__(kBlock) void radix_hist(const uint64_t *__restrict_
     for (int d = threadIdx.x; d < R; d += kBlock) h[d] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * (kBlock * ITEMS);
+    uint32_t guess = 0;
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = base + r * kBlock + threadIdx.x;
         const bool valid = i < n;
         const uint64_t k = valid ? keys[i] : 0ull;
-        const uint32_t d = BUCKET ? bucket_of<R>(k & kKeyMask40, spl) : (uint32_t)(k >> shift) & (R - 1);
+        uint32_t d;
+        if (BUCKET) {
+            // The bodies arrive almost in order: a key 256 places further on lies in the same bucket as the last one, or
+            // the next.  Two independent LDS reads confirm that for the whole wave; the search (eight or ten
+            // DEPENDENT reads) runs only where a lane's guess fails.
+            const uint64_t kk = k & kKeyMask40;
+            bool ok = false;
+            if (r > 0) ok = spl[guess] <= kk && (guess + 1 == (uint32_t)R || kk < spl[guess + 1]);
+            if (r > 0 && __ballot(valid && !ok) == 0ull) d = guess;   // uniform
+            else d = bucket_of<R>(kk, spl);
+            guess = d;
+        } else {
+            d = (uint32_t)(k >> shift) & (R - 1);
+        }
         if (BUCKET && valid) dig16[i] = (uint16_t)d;            // the scatter reads it back instead of searching again
         wave_count_digit<BUCKET>(h, d, valid);
     }

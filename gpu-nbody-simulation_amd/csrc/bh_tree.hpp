@@ -73,6 +73,12 @@ __global__ __launch_bounds__(kBlock) void bounds_partial(const Real2 *__restrict
     }
 }
 
+__global__ void bounds_slots_reset(double *slots)                // one wave: records back to +-inf, reader counter to 0
+{
+    double *w = slots + 4 * threadIdx.x;
+    w[0] = INFINITY; w[1] = -INFINITY; w[2] = INFINITY; w[3] = -INFINITY;
+}
+
 // final reduction + the padding of project.cu:553-570; also clears the per-step counters
 __global__ __launch_bounds__(kBlock) void bounds_final(const double *__restrict__ partial, int nb,
                                                         double *__restrict__ box, TreeCounters *ctr, int Dm)
@@ -211,13 +217,43 @@ __device__ __forceinline__ uint64_t key_of_fast(double x, double y, double x0, d
 // the splitters cut the new keys into near-equal buckets, whatever happened to the root box in between.
 template <typename Real2, bool HILBERT, bool PACK = false>
 __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ pos,
-                                                       const double *__restrict__ box,
+                                                       double *box_global,
                                                        uint64_t *__restrict__ keys,
                                                        uint32_t *__restrict__ idx, int64_t n, int Dm,
                                                        const float2 *__restrict__ samples = nullptr,
                                                        uint64_t *__restrict__ splitters = nullptr, int nb = 0,
-                                                       int ns = 0)
+                                                       int ns = 0, double *slots = nullptr, TreeCounters *ctr = nullptr)
 {
+    // slots != nullptr: the root box is not in memory yet -- the previous walk left its bounds in kBoundSlots
+    // records (bh_bounds.hpp).  Every workgroup reduces them and pads the box as bounds_final does
+    // (project.cu:553-570), workgroup 0 also writes it out and clears the step's counters for the kernels that
+    // follow; prep_kernel, two launches on, puts the slots back to +-inf for the next walk.  (A counter of readers
+    // that let the last workgroup do that here made this kernel 51 us instead of 10: 4,100 atomics on one word.)
+    __shared__ double s_box[8];
+    const double *box = box_global;
+    if (slots != nullptr) {
+        if (threadIdx.x < kWave) {
+            const double *sl = slots + 4 * threadIdx.x;
+            const double xlo = wave_min(sl[0]), xhi = wave_max(sl[1]), ylo = wave_min(sl[2]), yhi = wave_max(sl[3]);
+            if (threadIdx.x < 2) {                               // lane a: axis a (four fp64 divisions in a row otherwise)
+                const double ex = xhi - xlo, ey = yhi - ylo;
+                const double span = (ex < ey) ? ey : ex;
+                double pad = 0.1 * span;
+                if (span == 0.0) pad = 1e-6;
+                const int a = threadIdx.x;
+                s_box[2 * a] = (a ? ylo : xlo) - pad; s_box[2 * a + 1] = (a ? yhi : xhi) + pad;
+                write_key_consts_axis(s_box, a, Dm);
+            }
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) box_global[k] = s_box[k];
+            ctr->n_internal = 0; ctr->overflow = 0;
+            ctr->visits = 0; ctr->interactions = 0; ctr->wave_nodes = 0; ctr->wave_quads = 0;
+        }
+        box = s_box;
+    }
     const double x0 = box[0], x1 = box[1], y0 = box[2], y1 = box[3];
     const int nsb = (samples != nullptr) ? ns / kWave : 0;      // extra workgroups in front of the key workgroups
     if ((int)blockIdx.x < nsb) {
@@ -299,8 +335,13 @@ __global__ __launch_bounds__(kBlock) void prep_kernel(const uint64_t *__restrict
                                                        uint32_t *__restrict__ bsum_u32,
                                                        SReal2 *__restrict__ spos, SReal *__restrict__ smass,
                                                        d3 *__restrict__ terms, d3 *__restrict__ bsum_d3,
-                                                       uint64_t *__restrict__ coarse, int64_t n, int Dm)
+                                                       uint64_t *__restrict__ coarse, int64_t n, int Dm,
+                                                       double *slots_reset = nullptr)
 {
+    if (slots_reset != nullptr && blockIdx.x == 0 && threadIdx.x < kBoundSlots) {   // (keys_kernel has consumed them: bh_bounds.hpp)
+        double *w = slots_reset + 4 * threadIdx.x;
+        w[0] = INFINITY; w[1] = -INFINITY; w[2] = INFINITY; w[3] = -INFINITY;
+    }
     __shared__ uint32_t smu[kWavesPerBlock + 1];
     __shared__ d3 smd[kWavesPerBlock + 1];
     const int64_t base = (int64_t)blockIdx.x * (kBlock * ITEMS);

@@ -44,6 +44,7 @@ struct WalkFastArgs {
     int32_t part;
     float2 *acc_part;
     int64_t forest_base, let_cap;
+    double *slots;                 // bh_bounds.hpp: running bounds records of this launch's workgroups (with `partial`), may be null
     uint32_t *body_counts;         // counting variant (BH_FLAG_WALK_STATS): accepted force evaluations per body, added
                                    // atomically at the body's device slot (the engine zeroes it); may be null
 };

@@ -909,9 +909,10 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
             if (lane == 0) {
                 double *o = e.partial + 4 * (size_t)lb;
                 o[0] = xlo; o[1] = xhi; o[2] = ylo; o[3] = yhi;
+                if (e.slots) bounds_to_slot(xlo, xhi, ylo, yhi, e.slots, (uint32_t)lb);
             }
         }
-    } else if (e.partial) block_bounds_to_partial(valid, bx, by, e.partial + 4 * (size_t)lb);
+    } else if (e.partial) block_bounds_to_partial(valid, bx, by, e.partial + 4 * (size_t)lb, e.slots);
 #ifdef BHGPU_EXPERIMENTS
     if (e.timeline && lane == 0) {                              // per wave: start, end (10 ns ticks), hardware id, cost
         const int64_t wv = (int64_t)blockIdx.x * (blockDim.x >> 6) + w;
