@@ -292,7 +292,8 @@ int enqueue_build_t(bh_ctx *c)
         if (pack)
             hipLaunchKernelGGL((keys_kernel<Real2, true, true>), dim3(blocks_for(n, kBlock) + (bucket ? ns / kWave : 0)), dim3(kBlock),
                                0, st, pos, c->box, c->keys[0], c->vals[0], n, Dm,
-                               bucket ? (const float2 *)c->spos : nullptr, c->splitters, nb, ns, slots, c->ctr);
+                               bucket ? (const float2 *)c->spos : nullptr, c->splitters, nb, ns, slots, c->ctr,
+                               bucket ? c->bsum_sort : nullptr, bucket ? nb : 0);
         else if (c->hilbert)
             hipLaunchKernelGGL((keys_kernel<Real2, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
                                c->box, c->keys[0], c->vals[0], n, Dm, nullptr, nullptr, 0, 0, slots, c->ctr);
@@ -324,8 +325,7 @@ int enqueue_build_t(bh_ctx *c)
             auto pass = [&](auto bits_tag) {
                 constexpr int NBITS = decltype(bits_tag)::value;
                 hipLaunchKernelGGL((radix_hist<SI, NBITS, true>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->radix_counts, n,
-                                   0, (int)nbl, c->splitters, c->sort_dig);
-                hipLaunchKernelGGL(radix_rowscan, dim3(1 << NBITS), dim3(kBlock), 0, st, c->radix_counts, c->bsum_sort, (int)nbl);
+                                   0, (int)nbl, c->splitters, c->sort_dig, c->bsum_sort);
                 hipLaunchKernelGGL((radix_scatter_w<SI, NBITS, 1, true>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->vals[0],
                                    c->keys[1], c->vals[1], c->radix_counts, c->bsum_sort, n, 0, (int)nbl, c->sort_dig,
                                    c->bsum_sort + kBucketStartOffset);

@@ -117,7 +117,8 @@ __global__ __launch_bounds__(kBlock) void radix_hist(const uint64_t *__restrict_
                                                       uint32_t *__restrict__ counts, int64_t n,
                                                       int shift, int nblocks,
                                                       const uint64_t *__restrict__ splitters = nullptr,
-                                                      uint16_t *__restrict__ dig16 = nullptr)
+                                                      uint16_t *__restrict__ dig16 = nullptr,
+                                                      uint32_t *__restrict__ row_total = nullptr)
 {
     constexpr int R = 1 << BITS;
     __shared__ uint32_t h[R];
@@ -157,7 +158,14 @@ __global__ __launch_bounds__(kBlock) void radix_hist(const uint64_t *__restrict_
         wave_count_digit<BUCKET>(h, d, valid);
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < R; d += kBlock) counts[(int64_t)d * nblocks + blockIdx.x] = h[d];
+    for (int d = threadIdx.x; d < R; d += kBlock) {
+        const uint32_t v = h[d];
+        counts[(int64_t)d * nblocks + blockIdx.x] = v;
+        // BUCKET: the bucket totals are summed here (keys_kernel zeroed them) and the scatter adds up the few rows it
+        // needs itself -- the keys arrive almost in order, a tile meets one or two buckets -- so this pass has no
+        // radix_rowscan launch between its two kernels
+        if (BUCKET && v) atomicAdd(&row_total[d], v);
+    }
 }
 
 
@@ -205,6 +213,8 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
     // per wave: digit -> mask of the lanes that hold it in the current round (see bucket_sort_lds below: an LDS
     // OR + read + clear per key instead of ~8 vector instructions per digit bit of ballot matching)
     __shared__ uint64_t match[kWavesPerBlock][R];
+    constexpr int kRowsTogether = 8;
+    __shared__ uint32_t s_np, s_plist[kRowsTogether], s_before[kRowsTogether];
     const int t = threadIdx.x, w = wave_id(), l = lane_id();
     for (int d = t; d < R; d += kBlock)
 #pragma unroll
@@ -261,10 +271,50 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
         uint32_t all;
         uint32_t digit_base = block_exclusive_sum(tsum, sm, all);
         uint32_t lstart = block_exclusive_sum(csum, sm, all);
+        if (BUCKET) {
+            // offs holds the histogram's raw counts: the keys of bucket d in the tiles before this one are the sum of row
+            // d up to this tile.  The buckets this tile meets -- one or two in steady motion -- are listed, and the
+            // workgroup adds up their rows one after the other, 256 entries at a time; a tile that meets more than
+            // kRowsTogether buckets (disorder) lets every thread add up the rows of its own digits instead.
+            if (t == 0) s_np = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < DPT; ++j)
+                if (cnt[j]) { const uint32_t k = atomicAdd(&s_np, 1u); if (k < (uint32_t)kRowsTogether) s_plist[k] = (uint32_t)(DPT * t + j); }
+            __syncthreads();
+            const uint32_t np = s_np;
+            if (np <= (uint32_t)kRowsTogether) {
+                for (uint32_t k = 0; k < np; ++k) {
+                    const uint32_t d = s_plist[k];
+                    const uint32_t *row = offs + (int64_t)d * nblocks;
+                    uint32_t part = 0;
+                    for (uint32_t b = (uint32_t)t; b < blockIdx.x; b += kBlock) part += row[b];
+                    uint32_t total;
+                    (void)block_exclusive_sum(part, sm, total);
+                    if (t == 0) s_before[k] = total;
+                }
+                __syncthreads();
+            }
+        }
 #pragma unroll
         for (int j = 0; j < DPT; ++j) {
             const int d = DPT * t + j;
-            gdelta[d] = (int32_t)(digit_base + offs[(int64_t)d * nblocks + blockIdx.x]) - (int32_t)lstart;
+            uint32_t before = 0;                                // keys of digit d in the tiles before this one
+            if (BUCKET) {
+                if (cnt[j]) {
+                    const uint32_t np = s_np;
+                    if (np <= (uint32_t)kRowsTogether) {
+                        for (uint32_t k = 0; k < np; ++k) before = (s_plist[k] == (uint32_t)d) ? s_before[k] : before;
+                    } else {
+                        const uint32_t *row = offs + (int64_t)d * nblocks;
+#pragma unroll 8
+                        for (uint32_t b = 0; b < blockIdx.x; ++b) before += row[b];
+                    }
+                }
+            } else {
+                before = offs[(int64_t)d * nblocks + blockIdx.x];
+            }
+            gdelta[d] = (int32_t)(digit_base + before) - (int32_t)lstart;
             if (BUCKET && blockIdx.x == 0) bucket_start[d] = digit_base;   // where bucket d begins: bucket_sort_kernel reads it
             uint32_t run = lstart;
 #pragma unroll

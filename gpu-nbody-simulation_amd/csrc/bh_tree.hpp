@@ -222,8 +222,11 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
                                                        uint32_t *__restrict__ idx, int64_t n, int Dm,
                                                        const float2 *__restrict__ samples = nullptr,
                                                        uint64_t *__restrict__ splitters = nullptr, int nb = 0,
-                                                       int ns = 0, double *slots = nullptr, TreeCounters *ctr = nullptr)
+                                                       int ns = 0, double *slots = nullptr, TreeCounters *ctr = nullptr,
+                                                       uint32_t *__restrict__ zero_words = nullptr, int n_zero = 0)
 {
+    if (blockIdx.x == 0)                                         // (the bucket totals the histogram launch adds into: bh_sort.hpp)
+        for (int k = threadIdx.x; k < n_zero; k += kBlock) zero_words[k] = 0u;
     // slots != nullptr: the root box is not in memory yet -- the previous walk left its bounds in kBoundSlots
     // records (bh_bounds.hpp).  Every workgroup reduces them and pads the box as bounds_final does
     // (project.cu:553-570), workgroup 0 also writes it out and clears the step's counters for the kernels that
