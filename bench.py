@@ -37,9 +37,12 @@ NODE_BYTES = 20         # fp32 node: one quarter of the 80-byte sibling-quad rec
 # with 8 waves per SIMD by scripts/calib/issue_calib.hip (profiles/r02_final/issue_calib.txt): plain fp32
 # VALU 2.2; VALU with an SGPR operand, v_pk_*_f32, v_cmp/v_cmpx, v_writelane, v_readfirstlane 4.1-4.3;
 # v_rsq_f32 8.3.  Per evaluated child the loop issues v_pk_add(s) + v_mul + v_fmac + v_cmpx + v_rsq +
-# v_mul(s) + 2 v_mul + 2 v_fmac; per quad 3 v_readfirstlane (pop) and ~1 push of 3 v_writelane.
+# v_mul(s) + 2 v_mul + 2 v_fmac; per quad the stack traffic.  Round 3's loop keeps the first opened child of a
+# quad in scalar registers (no push, no pop): PMC counts 169.5 M vector instructions per launch for 14.73 M
+# children and 4.43 M quads (profiles/r03_final/pmc_summary.csv), i.e. 10 per child and 5.0 per quad -- 2.5
+# v_readlane + 2.5 v_writelane on average where round 2 had 3 + 3.
 VALU_CYCLES_PER_CHILD = 4.2 + 2.2 + 2.2 + 4.3 + 8.3 + 4.2 + 2.2 + 2.2 + 2.2 + 2.2
-VALU_CYCLES_PER_QUAD = 3 * 4.1 + 3 * 4.2
+VALU_CYCLES_PER_QUAD = 2.5 * 4.1 + 2.5 * 4.2
 N_SIMDS, SHADER_CLOCK_HZ = 1024, 2.4e9
 
 

@@ -273,7 +273,7 @@ int enqueue_build_t(bh_ctx *c)
     if (n > 0) {
         // 2. keys by fp64 bisection, 3. stable radix sort
         // keys of <= 40 bits for <= 2^24 bodies carry the body index in the key word through the sort
-        const bool pack = c->hilbert && Dm >= 1 && 2 * Dm <= kPackShift && n <= ((int64_t)1 << (64 - kPackShift)) && c->sort_wave_rank
+        const bool pack = Dm >= 1 && 2 * Dm <= kPackShift && n <= ((int64_t)1 << (64 - kPackShift)) && c->sort_wave_rank
 #ifdef BHGPU_EXPERIMENTS
                           && !c->sort_onesweep
 #endif
@@ -281,7 +281,7 @@ int enqueue_build_t(bh_ctx *c)
         // bucket sort (bh_sort.hpp): one counting pass by splitters from the previous build + one in-LDS sort per bucket
         bool bucket = false;
         if constexpr (!EXACT)
-            bucket = pack && n >= 2 && n <= kBucketMaxNBig && (c->sort_bucket == 2 || (c->sort_bucket == 1 && c->samples_n == n));
+            bucket = pack && c->hilbert && n >= 2 && n <= kBucketMaxNBig && (c->sort_bucket == 2 || (c->sort_bucket == 1 && c->samples_n == n));
         const int nb = (n <= kBucketMaxN) ? kBuckets : kBucketsBig;
         // sample positions behind the splitters: two per bucket where the key workgroups run long enough to hide the
         // sample workgroups (256 buckets: above 262k bodies; 1,024 buckets: above 3M), one per bucket otherwise
@@ -289,7 +289,10 @@ int enqueue_build_t(bh_ctx *c)
                                         : ((n > (int64_t)3 << 20) ? kMaxSplitSamples : kBucketsBig);
         static_assert(kBucketMaxN == (int64_t)1 << 20 && kBucketMaxNBig == (int64_t)1 << 22, "BASELINE configs 3 and 4 fit");
         c->last_sort_bucket = bucket; c->last_sort_packed = pack;
-        if (pack)
+        if (pack && !c->hilbert)                                 // (exact mode and BH_HILBERT=0: child-index keys, packed all the same)
+            hipLaunchKernelGGL((keys_kernel<Real2, false, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
+                               c->box, c->keys[0], c->vals[0], n, Dm, nullptr, nullptr, 0, 0, slots, c->ctr);
+        else if (pack)
             hipLaunchKernelGGL((keys_kernel<Real2, true, true>), dim3(blocks_for(n, kBlock) + (bucket ? ns / kWave : 0)), dim3(kBlock),
                                0, st, pos, c->box, c->keys[0], c->vals[0], n, Dm,
                                bucket ? (const float2 *)c->spos : nullptr, c->splitters, nb, ns, slots, c->ctr,
