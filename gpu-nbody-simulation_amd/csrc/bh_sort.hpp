@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
     // per wave: digit -> mask of the lanes that hold it in the current round (see bucket_sort_lds below: an LDS
     // OR + read + clear per key instead of ~8 vector instructions per digit bit of ballot matching)
     __shared__ uint64_t match[kWavesPerBlock][R];
-    constexpr int kRowsTogether = 8;
+    constexpr int kRowsTogether = 64;
     __shared__ uint32_t s_np, s_plist[kRowsTogether], s_before[kRowsTogether];
     const int t = threadIdx.x, w = wave_id(), l = lane_id();
     for (int d = t; d < R; d += kBlock)
@@ -273,9 +273,10 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
         uint32_t lstart = block_exclusive_sum(csum, sm, all);
         if (BUCKET) {
             // offs holds the histogram's raw counts: the keys of bucket d in the tiles before this one are the sum of row
-            // d up to this tile.  The buckets this tile meets -- one or two in steady motion -- are listed, and the
-            // workgroup adds up their rows one after the other, 256 entries at a time; a tile that meets more than
-            // kRowsTogether buckets (disorder) lets every thread add up the rows of its own digits instead.
+            // d up to this tile.  The buckets this tile meets -- one or two in steady motion, a dozen when the bodies
+            // have drifted for sixteen builds since the state was last put in order -- are listed, and the waves add up
+            // their rows, four rows per wave at a time; a tile that meets more than kRowsTogether buckets (disorder) lets
+            // every thread add up the rows of its own digits instead.
             if (t == 0) s_np = 0u;
             __syncthreads();
 #pragma unroll
@@ -283,15 +284,31 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
                 if (cnt[j]) { const uint32_t k = atomicAdd(&s_np, 1u); if (k < (uint32_t)kRowsTogether) s_plist[k] = (uint32_t)(DPT * t + j); }
             __syncthreads();
             const uint32_t np = s_np;
-            if (np <= (uint32_t)kRowsTogether) {
+            if (np <= 2u) {                                      // steady motion: the whole workgroup on one row, then the other
                 for (uint32_t k = 0; k < np; ++k) {
-                    const uint32_t d = s_plist[k];
-                    const uint32_t *row = offs + (int64_t)d * nblocks;
+                    const uint32_t *row = offs + (int64_t)s_plist[k] * nblocks;
                     uint32_t part = 0;
                     for (uint32_t b = (uint32_t)t; b < blockIdx.x; b += kBlock) part += row[b];
                     uint32_t total;
                     (void)block_exclusive_sum(part, sm, total);
                     if (t == 0) s_before[k] = total;
+                }
+                __syncthreads();
+            } else if (np <= (uint32_t)kRowsTogether) {
+                for (uint32_t k0 = 4u * (uint32_t)w; k0 < np; k0 += 4u * kWavesPerBlock) {   // four rows per wave at a time
+                    const uint32_t *row[4];
+                    uint32_t part[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) row[j] = offs + (int64_t)s_plist[(k0 + j < np) ? k0 + j : k0] * nblocks;
+                    for (uint32_t b = (uint32_t)l; b < blockIdx.x; b += kWave) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) part[j] += row[j][b];                   // (independent loads)
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t inc = wave_inclusive_sum(part[j]);
+                        if (l == kWave - 1 && k0 + j < np) s_before[k0 + j] = inc;
+                    }
                 }
                 __syncthreads();
             }

@@ -4,7 +4,7 @@ PAT=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 for v in "" "$@"; do
   OUT=gpurun_out/kl_${v:-product}
-  mkdir -p $OUT
+  rm -rf $OUT/trace; mkdir -p $OUT
   if [ -n "$v" ]; then export BHGPU_LIB_OPT_IN=1 BHGPU_LIB=$PWD/gpu-nbody-simulation_amd/build/libbhgpu_$v.so; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 scripts/run_steps.py ${RUN_ARGS:---steps 30} > $OUT/trace.log 2>&1
   echo "== ${v:-product}: $(grep '^{' $OUT/trace.log)"

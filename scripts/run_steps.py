@@ -31,4 +31,4 @@ with G.BarnesHutEngine(G.BhConfig(capacity=a.n, theta=a.theta, max_depth=21, pre
     st = e.stats()
 print(json.dumps({"n": a.n, "init": a.init, "drift": a.drift, "ms_per_step": round(dt, 4), "build_ms": round(st.build_ms, 4),
                   "walk_ms": round(st.walk_ms, 4), "keys_ms": round(st.keys_ms, 4), "sort_ms": round(st.sort_ms, 4),
-                  "scan_ms": round(st.scan_ms, 4), "nodes_ms": round(st.nodes_ms, 4), "sort_spill_buckets": st.sort_spill_buckets}))
+                  "scan_ms": round(st.scan_ms, 4), "nodes_ms": round(st.nodes_ms, 4), "sort_spill_buckets": st.sort_spill_buckets, "sort_rerun_buckets": st.sort_rerun_buckets}))
