@@ -751,9 +751,18 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
 #if defined(BHGPU_EXPERIMENTS) && defined(BH_NODES_EXPT2)
     if (BH_NODES_EXPT2 == 1) return;                            // timing experiment: launch + window only
 #endif
+    // (a select between the two pointers compiles to ONE flat load from a generic address -- through the vector memory
+    // path even when the address is in LDS, with 64-bit address arithmetic; almost every read is inside the window, so
+    // the window is read with a plain LDS instruction and the rare lane outside it is patched up under a uniform test)
     auto K = [&](int32_t j) -> uint64_t {
         const int32_t k = j - wlo;
-        return (k >= 0 && k < kKeyWin) ? wkeys[k] : keys[j];
+        const bool in = (uint32_t)k < (uint32_t)kKeyWin;
+        uint64_t v = wkeys[in ? k : 0];
+        if (__ballot(!in) != 0ull) {
+            asm volatile("" : "+v"(v));                         // (keeps the compiler from merging the two loads into a flat one again)
+            if (!in) v = keys[j];
+        }
+        return v;
     };
 
     // first j in [lo, hi) with (key_j >> sh) >= target, for NT ascending targets at once.  The kernel's time
@@ -762,7 +771,7 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     // together (3 * NT independent loads in flight, log4 instead of log2 rounds; round 1's one-probe
     // bisection of the end and of the three child boundaries one after the other was a chain of ~80 loads).
     // Large ranges are narrowed on the sampled index first: after that the range is < 2*kCoarse wide.
-    auto search = [&](auto nt_tag, int32_t lo0, int32_t hi0, int sh, const uint64_t *target, int32_t *res) {
+    auto search = [&](auto nt_tag, auto keyfn, int32_t lo0, int32_t hi0, int sh, const uint64_t *target, int32_t *res) {
         constexpr int NT = decltype(nt_tag)::value;
         int32_t lo[NT], hi[NT];
 #pragma unroll
@@ -811,7 +820,7 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
 #pragma unroll
             for (int c = 0; c < NT; ++c) {
                 p2[c] = (int32_t)(((uint32_t)lo[c] + (uint32_t)hi[c]) >> 1);
-                k2[c] = (hi[c] > lo[c]) ? K(p2[c]) : 0ull;
+                k2[c] = (hi[c] > lo[c]) ? keyfn(p2[c]) : 0ull;
             }
             more = false;
 #pragma unroll
@@ -827,7 +836,7 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     };
     auto lower_bound = [&](int32_t lo, int32_t hi, int sh, uint64_t target) -> int32_t {
         int32_t r;
-        search(std::integral_constant<int, 1>{}, lo, hi, sh, &target, &r);
+        search(std::integral_constant<int, 1>{}, K, lo, hi, sh, &target, &r);
         return r;
     };
 
@@ -862,7 +871,17 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
         const uint64_t cell_hi = (pfx + 1) << sh;                // keys are sorted: outside the cell <=> key >= cell_hi
         uint64_t nk[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) nk[j] = (i + 1 + j < n) ? K(i + 1 + j) : ~0ull;
+        for (int j = 0; j < 8; ++j) nk[j] = 0ull;
+        // (wave-uniform test: when every lane's eight keys lie inside the window -- nearly always -- they are eight plain LDS
+        // reads at constant offsets from one address, not eight guarded reads with a branch and a fallback each)
+        const int32_t k1 = i + 1 - wlo;
+        if (__ballot(!(k1 >= 0 && k1 + 8 <= kKeyWin && i + 8 < n)) == 0ull) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) nk[j] = wkeys[k1 + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) nk[j] = (i + 1 + j < n) ? K(i + 1 + j) : ~0ull;
+        }
         int inside = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) inside += (nk[j] < cell_hi) ? 1 : 0;
@@ -912,10 +931,33 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     // independent of each other, and this kernel's time is the length of its per-thread chain of
     // dependent memory accesses (3 rounds of resident workgroups x one chain at N = 1M)
     bnd[0] = i; bnd[4] = e;
+    // every key this cell still needs lies in [i - 1, e): when that range is inside the window for all the wave's cells
+    // -- nearly always -- the reads below are plain LDS reads (KF), without the guard and the fallback of K
+    auto KF = [&](int32_t j) -> uint64_t { return wkeys[j - wlo]; };
+    const bool cells_in_window = __ballot(!(i - 1 >= wlo && e - wlo <= kKeyWin)) == 0ull;   // uniform
     if (!have_bnd) {
         const uint64_t tg[3] = {(pfx << 2) | 1ull, (pfx << 2) | 2ull, (pfx << 2) | 3ull};
-        if (!expt_skip) search(std::integral_constant<int, 3>{}, i, e, shc, tg, &bnd[1]);
-        else bnd[1] = bnd[2] = bnd[3] = e;
+        if (expt_skip) bnd[1] = bnd[2] = bnd[3] = e;
+        else if (cells_in_window) {
+            // branch-free bisection of the three child boundaries inside the window: every round reads one key per
+            // boundary whether or not that search is still open (a closed one re-reads its end point: at worst entry
+            // kKeyWin, inside the LDS block) and moves its bounds by selects -- the guarded form above compiles to
+            // an EXEC-mask branch around every read and every update
+            int32_t lo3[3] = {i, i, i}, hi3[3] = {e, e, e};
+            const uint64_t t3[3] = {tg[0] << shc, tg[1] << shc, tg[2] << shc};
+            while ((hi3[0] > lo3[0]) | (hi3[1] > lo3[1]) | (hi3[2] > lo3[2])) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int32_t pm = (int32_t)(((uint32_t)lo3[c] + (uint32_t)hi3[c]) >> 1);
+                    const uint64_t km = wkeys[pm - wlo];
+                    const bool open = hi3[c] > lo3[c], ge = km >= t3[c];
+                    hi3[c] = (open && ge) ? pm : hi3[c];
+                    lo3[c] = (open && !ge) ? pm + 1 : lo3[c];
+                }
+            }
+            bnd[1] = lo3[0]; bnd[2] = lo3[1]; bnd[3] = lo3[2];
+        }
+        else search(std::integral_constant<int, 3>{}, K, i, e, shc, tg, &bnd[1]);
     }
     d3 ps[5];
     uint32_t offc[4];
@@ -938,8 +980,13 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
         const int32_t ncc = bnd[c + 1] - bc;
         const bool sub = ncc > 1 && d + 1 < Dm;                  // a subdivided child: its rank comes from off and its keys
         offc[c] = sub ? off[bc] : 0u;
-        kcur[c] = sub ? K(bc) : 0ull;
-        kprev[c] = (sub && bc > 0) ? K(bc - 1) : 0ull;
+        if (cells_in_window) {
+            kcur[c] = sub ? KF(bc) : 0ull;
+            kprev[c] = (sub && bc > 0) ? KF(bc - 1) : 0ull;
+        } else {
+            kcur[c] = sub ? K(bc) : 0ull;
+            kprev[c] = (sub && bc > 0) ? K(bc - 1) : 0ull;
+        }
         p1[c] = (ncc == 1) ? spos[bc] : float2{0.f, 0.f};
         m1[c] = (ncc == 1) ? smass[bc] : 0.f;
     }
