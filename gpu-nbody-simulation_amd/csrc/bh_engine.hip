@@ -289,20 +289,25 @@ int enqueue_build_t(bh_ctx *c)
                                         : ((n > (int64_t)3 << 20) ? kMaxSplitSamples : kBucketsBig);
         static_assert(kBucketMaxN == (int64_t)1 << 20 && kBucketMaxNBig == (int64_t)1 << 22, "BASELINE configs 3 and 4 fit");
         c->last_sort_bucket = bucket; c->last_sort_packed = pack;
-        if (pack && !c->hilbert)                                 // (exact mode and BH_HILBERT=0: child-index keys, packed all the same)
-            hipLaunchKernelGGL((keys_kernel<Real2, false, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
-                               c->box, c->keys[0], c->vals[0], n, Dm, nullptr, nullptr, 0, 0, slots, c->ctr);
-        else if (pack)
-            hipLaunchKernelGGL((keys_kernel<Real2, true, true>), dim3(blocks_for(n, kBlock) + (bucket ? ns / kWave : 0)), dim3(kBlock),
-                               0, st, pos, c->box, c->keys[0], c->vals[0], n, Dm,
-                               bucket ? (const float2 *)c->spos : nullptr, c->splitters, nb, ns, slots, c->ctr,
-                               bucket ? c->bsum_sort : nullptr, bucket ? nb : 0);
-        else if (c->hilbert)
-            hipLaunchKernelGGL((keys_kernel<Real2, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
-                               c->box, c->keys[0], c->vals[0], n, Dm, nullptr, nullptr, 0, 0, slots, c->ctr);
-        else
-            hipLaunchKernelGGL((keys_kernel<Real2, false>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, st, pos,
-                               c->box, c->keys[0], c->vals[0], n, Dm, nullptr, nullptr, 0, 0, slots, c->ctr);
+        {
+            const unsigned nkb = blocks_for(n, kBlock);
+            auto keys_launch = [&](auto hil, auto pk, auto fs) {
+                constexpr bool H = decltype(hil)::value, P = decltype(pk)::value, F = decltype(fs)::value;
+                const bool smp = H && P && bucket;                  // (the splitter workgroups exist in the packed Hilbert variant only)
+                hipLaunchKernelGGL((keys_kernel<Real2, H, P, F>), dim3(nkb + (smp ? ns / kWave : 0)), dim3(kBlock), 0, st, pos, c->box,
+                                   c->keys[0], c->vals[0], n, Dm, smp ? (const float2 *)c->spos : nullptr, c->splitters, nb, ns,
+                                   slots, c->ctr, smp ? c->bsum_sort : nullptr, smp ? nb : 0);
+            };
+            using T = std::true_type; using Fz = std::false_type;
+            // (exact mode and BH_HILBERT=0: child-index keys, packed all the same)
+            if (from_slots) {
+                if (pack && c->hilbert) keys_launch(T{}, T{}, T{}); else if (pack) keys_launch(Fz{}, T{}, T{});
+                else if (c->hilbert) keys_launch(T{}, Fz{}, T{}); else keys_launch(Fz{}, Fz{}, T{});
+            } else {
+                if (pack && c->hilbert) keys_launch(T{}, T{}, Fz{}); else if (pack) keys_launch(Fz{}, T{}, Fz{});
+                else if (c->hilbert) keys_launch(T{}, Fz{}, Fz{}); else keys_launch(Fz{}, Fz{}, Fz{});
+            }
+        }
         if (c->time_groups) (void)hipEventRecord(c->ev_grp[0], st);
         const unsigned nbl = blocks_for(n, ITEMS == kItems ? kSortTile : TILE);
         int cur = 0;

@@ -540,14 +540,15 @@ __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in,
         // top bits by counting.  Position = own position + (later keys of the run that are smaller) - (earlier keys of
         // the run that are larger); keys equal in all bits keep their order.
         const uint64_t lowmask = (1ull << first) - 1ull;
-        uint32_t npos[ITEMS];
         bool too_long = false;
+        // (every key goes straight to its place in memory, at most kFixRun places from a coalesced store; should a run turn
+        // out too long, the full sort below overwrites all of it)
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const int i = t + r * kBsThreads;
-            npos[r] = (uint32_t)i;
             if (i < m) {
-                const uint64_t kk = skey[i] & kKeyMask40;
+                const uint64_t word = skey[i];
+                const uint64_t kk = word & kKeyMask40;
                 const uint64_t top = kk >> first, low = kk & lowmask;
                 int delta = 0, j;
                 for (j = i - 1; j >= 0 && i - j <= kFixRun; --j) {
@@ -562,21 +563,13 @@ __device__ __forceinline__ void bucket_sort_lds(const uint64_t *__restrict__ in,
                     delta += ((q & lowmask) < low) ? 1 : 0;
                 }
                 too_long = too_long || (j < m && j - i > kFixRun);
-                key[r] = skey[i];
-                npos[r] = (uint32_t)(i + delta);
+                kout[i + delta] = kk + kmin;
+                vout[i + delta] = (uint32_t)(word >> kPackShift);
             }
         }
         if (too_long) *s_flag = 1u;
         __syncthreads();
-        if (*s_flag == 0u) {                                        // straight to memory, at most kFixRun places from a coalesced store
-#pragma unroll
-            for (int r = 0; r < ITEMS; ++r)
-                if (t + r * kBsThreads < m) {
-                    kout[npos[r]] = (key[r] & kKeyMask40) + kmin;
-                    vout[npos[r]] = (uint32_t)(key[r] >> kPackShift);
-                }
-            return;
-        }
+        if (*s_flag == 0u) return;
         // a long run: the full passes from the input (rare: bodies piled up on a few key values under a wide span)
         if (t == 0) atomicAdd(reruns, 1u);
 #pragma unroll

@@ -215,7 +215,7 @@ __device__ __forceinline__ uint64_t key_of_fast(double x, double y, double x0, d
 // of this build -- the keys, in THIS build's box, of the positions that stood at the ranks j * n / nb of the previous
 // build's sorted order (ns >= nb of them, powers of two), sorted; splitter 0 is 0.  Bodies move little between two builds, so
 // the splitters cut the new keys into near-equal buckets, whatever happened to the root box in between.
-template <typename Real2, bool HILBERT, bool PACK = false>
+template <typename Real2, bool HILBERT, bool PACK = false, bool FROM_SLOTS = false>
 __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ pos,
                                                        double *box_global,
                                                        uint64_t *__restrict__ keys,
@@ -227,14 +227,13 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
 {
     if (blockIdx.x == 0)                                         // (the bucket totals the histogram launch adds into: bh_sort.hpp)
         for (int k = threadIdx.x; k < n_zero; k += kBlock) zero_words[k] = 0u;
-    // slots != nullptr: the root box is not in memory yet -- the previous walk left its bounds in kBoundSlots
+    // FROM_SLOTS: the root box is not in memory yet -- the previous walk left its bounds in kBoundSlots
     // records (bh_bounds.hpp).  Every workgroup reduces them and pads the box as bounds_final does
     // (project.cu:553-570), workgroup 0 also writes it out and clears the step's counters for the kernels that
     // follow; prep_kernel, two launches on, puts the slots back to +-inf for the next walk.  (A counter of readers
     // that let the last workgroup do that here made this kernel 51 us instead of 10: 4,100 atomics on one word.)
-    __shared__ double s_box[8];
-    const double *box = box_global;
-    if (slots != nullptr) {
+    __shared__ double s_box[FROM_SLOTS ? 8 : 1];
+    if (FROM_SLOTS) {
         if (threadIdx.x < kWave) {
             const double *sl = slots + 4 * threadIdx.x;
             const double xlo = wave_min(sl[0]), xhi = wave_max(sl[1]), ylo = wave_min(sl[2]), yhi = wave_max(sl[3]);
@@ -255,9 +254,16 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
             ctr->n_internal = 0; ctr->overflow = 0;
             ctr->visits = 0; ctr->interactions = 0; ctr->wave_nodes = 0; ctr->wave_quads = 0;
         }
-        box = s_box;
     }
-    const double x0 = box[0], x1 = box[1], y0 = box[2], y1 = box[3];
+    // (a template parameter, not a run-time test: read through a pointer that is either in LDS or in memory the eight values
+    // become flat loads per lane; kept apart they are LDS broadcasts here and scalar loads there)
+    double x0, x1, y0, y1, bk4, bk5, bk6, bk7;
+    if (FROM_SLOTS) {
+        x0 = s_box[0]; x1 = s_box[1]; y0 = s_box[2]; y1 = s_box[3]; bk4 = s_box[4]; bk5 = s_box[5]; bk6 = s_box[6]; bk7 = s_box[7];
+    } else {
+        x0 = box_global[0]; x1 = box_global[1]; y0 = box_global[2]; y1 = box_global[3];
+        bk4 = box_global[4]; bk5 = box_global[5]; bk6 = box_global[6]; bk7 = box_global[7];
+    }
     const int nsb = (samples != nullptr) ? ns / kWave : 0;      // extra workgroups in front of the key workgroups
     if ((int)blockIdx.x < nsb) {
         // ns sample positions -> keys -> ranks by counting -> every (ns / nb)-th in rank order is a splitter.
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
         // and one bucket would get everything.)
         const int Ds = Dm, lg_ns = 31 - __clz(ns), lg_os = lg_ns - (31 - __clz(nb));
         const double side = (double)(1u << Ds), top = side - 1.0, down = 1.0 / (double)(1u << (Dm - Ds));
-        const double sx = (box[4] > 0.0) ? box[4] * down : side / (x1 - x0), sy = (box[5] > 0.0) ? box[5] * down : side / (y1 - y0);
+        const double sx = (bk4 > 0.0) ? bk4 * down : side / (x1 - x0), sy = (bk5 > 0.0) ? bk5 * down : side / (y1 - y0);
         float2 qs[kMaxSplitSamples / kBlock];                    // all of this thread's sample loads in flight at once
 #pragma unroll
         for (int k = 0; k < kMaxSplitSamples / kBlock; ++k) {
@@ -313,8 +319,8 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
     }
     const int64_t i = ((int64_t)blockIdx.x - nsb) * kBlock + threadIdx.x;
     if (i >= n) return;
-    const uint64_t k = HILBERT ? key_of_fast<HILBERT>((double)pos[i].x, (double)pos[i].y, x0, x1, y0, y1, Dm, box[4], box[5],
-                                                      box[6], box[7])
+    const uint64_t k = HILBERT ? key_of_fast<HILBERT>((double)pos[i].x, (double)pos[i].y, x0, x1, y0, y1, Dm, bk4, bk5,
+                                                      bk6, bk7)
                                : key_of<HILBERT>((double)pos[i].x, (double)pos[i].y, x0, x1, y0, y1, Dm);
     if (PACK) {
         keys[i] = k | ((uint64_t)i << kPackShift);

@@ -86,3 +86,29 @@ def test_the_one_wave_kernel_really_is_the_hand_written_loop(compiled):
     body = text[text.index(ONE_WAVE_ASM + ":"):]
     body = body[:body.index("s_endpgm", body.index("Ldone_"))]
     assert "s_load_dwordx16 s[48:63]" in body and "s_load_dwordx16 s[24:39]" in body and "v_cmpx_lt_f32_e32" in body
+
+
+def test_no_build_or_fp64_walk_kernel_uses_scratch(tmp_path):
+    """Every kernel of the engine unit (tree build, sorts, LET, exact and fp64 walks) keeps its working set in registers
+    and LDS: private_segment_fixed_size == 0 and no vector-register spills.  (Round 3: bucket_sort_kernel, whose 1,024-thread workgroups
+    cap it at 128 VGPRs, spilled 52 bytes per lane after the run fix-up of its short sort was added with two more
+    arrays per key; nothing failed -- the kernel was just slower than it had to be.)"""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(os.path.dirname(SRC), "bh_engine.hip")
+    out = tmp_path / "engine.s"
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-S", "--cuda-device-only",
+                        "-w", "-o", str(out), src], cwd=os.path.dirname(src), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+    seen = 0
+    for m in re.finditer(r"\.name:\s+(\S+)\n", text):
+        meta = text[m.start():m.start() + 3000]
+        if ".private_segment_fixed_size" not in meta:
+            continue
+        val = lambda key: int(re.search(key + r":\s+(\d+)", meta).group(1))
+        seen += 1
+        assert val(r"\.private_segment_fixed_size") == 0, m.group(1)
+        assert val(r"\.vgpr_spill_count") == 0, m.group(1)      # (SGPRs spilled to VGPR lanes cost a v_writelane, not memory)
+    assert seen >= 40                                              # (all instantiations were looked at)
