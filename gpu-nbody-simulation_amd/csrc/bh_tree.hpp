@@ -187,9 +187,29 @@ __device__ __forceinline__ uint64_t key_of(double x, double y, double x0, double
 // grid line, a body on the box edge, non-finite input: ~1 body in 10^8) takes key_of.  The curve digits
 // then come from the integer cell coordinates.  Same keys, bit for bit (tests: every tree comparison against
 // the oracle, and test_fast_keys_equal_the_bisection_keys on grid-line and box-edge positions).
+// Three levels of the curve per table look-up: entry [state << 6 | iy3 << 3 | ix3] = next state << 6 | the three digits
+// (the state machine above run over the three bit pairs, high bits first).  256 bytes, built by every key workgroup in
+// LDS (one entry per thread).  A level by itself is ~14 vector instructions (two bit extractions, two variable shifts of
+// the packed tables, the 64-bit shift-or of the key): 280 of keys_kernel's ~300 per body at 20 levels; three levels per
+// look-up are ~9 and one dependent LDS read.
+__device__ __forceinline__ uint32_t hilbert3_entry(uint32_t t)
+{
+    int state = (int)(t >> 6);
+    const uint32_t iy3 = (t >> 3) & 7u, ix3 = t & 7u;
+    uint32_t digits = 0;
+#pragma unroll
+    for (int l = 2; l >= 0; --l) {
+        const int c = (int)(((ix3 >> l) & 1u) | (((iy3 >> l) & 1u) << 1));
+        digits = (digits << 2) | (uint32_t)hilbert_digit(state, c);
+        state = hilbert_next(state, c);
+    }
+    return ((uint32_t)state << 6) | digits;
+}
+
 template <bool HILBERT>
 __device__ __forceinline__ uint64_t key_of_fast(double x, double y, double x0, double x1, double y0, double y1, int Dm,
-                                                double scale_x, double scale_y, double margin_x, double margin_y)
+                                                double scale_x, double scale_y, double margin_x, double margin_y,
+                                                const uint8_t *hil3 = nullptr)
 {
     const double side = (double)(1u << Dm);
     const double tx = (x - x0) * scale_x, ty = (y - y0) * scale_y;
@@ -202,7 +222,22 @@ __device__ __forceinline__ uint64_t key_of_fast(double x, double y, double x0, d
     const uint32_t ix = (uint32_t)fx, iy = (uint32_t)fy;
     uint64_t k = 0;
     int state = 0;
-    for (int l = Dm - 1; l >= 0; --l) {
+    int l = Dm - 1;
+    if (HILBERT && hil3 != nullptr) {
+        for (; (l + 1) % 3 != 0; --l) {                          // the one or two levels above a multiple of three
+            const int c = (int)(((ix >> l) & 1u) | (((iy >> l) & 1u) << 1));
+            k = (k << 2) | (uint64_t)hilbert_digit(state, c);
+            state = hilbert_next(state, c);
+        }
+        uint32_t st = (uint32_t)state;
+        for (; l >= 2; l -= 3) {
+            const uint32_t e = hil3[(st << 6) | (((iy >> (l - 2)) & 7u) << 3) | ((ix >> (l - 2)) & 7u)];
+            k = (k << 6) | (uint64_t)(e & 63u);
+            st = e >> 6;
+        }
+        return k;
+    }
+    for (; l >= 0; --l) {
         const int c = (int)(((ix >> l) & 1u) | (((iy >> l) & 1u) << 1));
         k = (k << 2) | (uint64_t)(HILBERT ? hilbert_digit(state, c) : c);
         state = hilbert_next(state, c);
@@ -317,10 +352,16 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
         if (part == 0 && (rank & ((1 << lg_os) - 1)) == 0) splitters[rank >> lg_os] = tagged >> 11;
         return;
     }
+    __shared__ uint8_t s_hil3[HILBERT ? 256 : 1];
+    if (HILBERT) {
+        static_assert(kBlock == 256, "one table entry per thread");
+        s_hil3[threadIdx.x] = (uint8_t)hilbert3_entry(threadIdx.x);
+        __syncthreads();
+    }
     const int64_t i = ((int64_t)blockIdx.x - nsb) * kBlock + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = HILBERT ? key_of_fast<HILBERT>((double)pos[i].x, (double)pos[i].y, x0, x1, y0, y1, Dm, bk4, bk5,
-                                                      bk6, bk7)
+                                                      bk6, bk7, s_hil3)
                                : key_of<HILBERT>((double)pos[i].x, (double)pos[i].y, x0, x1, y0, y1, Dm);
     if (PACK) {
         keys[i] = k | ((uint64_t)i << kPackShift);
