@@ -512,8 +512,13 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
                                    (double2 *)c->force, plo, phi, c->cfg.theta, c->cfg.G, c->cfg.dt,
                                    integrate ? 1 : 0, c->ctr, pp, stats ? c->body_counts : nullptr);
             };
-            if (c->compat) { if (stats) args(walk_f64_kernel<true, true>); else args(walk_f64_kernel<true, false>); }
-            else           { if (stats) args(walk_f64_kernel<false, true>); else args(walk_f64_kernel<false, false>); }
+            if (3 * c->Dm + 1 > kWave) {                         // (deeper than 21 levels: the two-tier stack)
+                if (c->compat) { if (stats) args(walk_f64_kernel<true, true, true>); else args(walk_f64_kernel<true, false, true>); }
+                else           { if (stats) args(walk_f64_kernel<false, true, true>); else args(walk_f64_kernel<false, false, true>); }
+            } else {
+                if (c->compat) { if (stats) args(walk_f64_kernel<true, true>); else args(walk_f64_kernel<true, false>); }
+                else           { if (stats) args(walk_f64_kernel<false, true>); else args(walk_f64_kernel<false, false>); }
+            }
         }
         per_partial = kF64Block;
         BH_HIP(c, hipGetLastError());

@@ -43,8 +43,22 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
 
     // evaluate one node for the lanes in `live`; returns the mask of lanes that must open it
     auto visit = [&](int32_t node, uint64_t live, int32_t &child_out) -> uint64_t {
-        const NodeD q = gd[node];
-        const LinkD k = ld[node];
+        // (both requests of a node issued together and waited for once; the compiler would fetch the mass and the links first
+        // and the centre only after the empty test -- two scalar round trips per visited node)
+        typedef int32_t v8i __attribute__((ext_vector_type(8)));
+        typedef int32_t v2i __attribute__((ext_vector_type(2)));
+        v8i qa; v2i ka;
+        {
+            const NodeD *pq = gd + node;
+            const LinkD *pk = ld + node;
+            asm volatile("s_load_dwordx8 %0, %2, 0x0\n\t"
+                         "s_load_dwordx2 %1, %3, 0x0\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&s"(qa), "=&s"(ka) : "s"(pq), "s"(pk) : "memory");
+        }
+        const NodeD q{__hiloint2double(qa[1], qa[0]), __hiloint2double(qa[3], qa[2]), __hiloint2double(qa[5], qa[4]),
+                      __hiloint2double(qa[7], qa[6])};
+        const LinkD k{ka[0], ka[1]};
         child_out = k.child;
         if (q.m <= 1e-15) return 0;                // project.cu:617
         const bool mine = (live >> lane) & 1ull;

@@ -50,7 +50,9 @@ __device__ __forceinline__ double w64_f64(int32_t lo, int32_t hi)
 #endif
 constexpr int kF64Block = BH_F64_BLOCK;
 
-template <bool COMPAT, bool STATS>
+// DEEP: trees deeper than 21 levels need more than 64 stack entries (3 * (max_depth - 1) + 1): a second register-lane
+// tier, and a test on every push and pop that the usual depth does without.
+template <bool COMPAT, bool STATS, bool DEEP = false>
 __global__ __launch_bounds__(kF64Block) void walk_f64_kernel(
     const NodeD *__restrict__ gd, const LinkD *__restrict__ ld, const uint32_t *__restrict__ perm,
     double2 *__restrict__ pos, double2 *__restrict__ vel, const double *__restrict__ mass,
@@ -72,23 +74,31 @@ __global__ __launch_bounds__(kF64Block) void walk_f64_kernel(
 #pragma clang diagnostic ignored "-Wold-style-cast"
     const char BH64_CONSTANT *cg = (const char BH64_CONSTANT *)gd;
     const char BH64_CONSTANT *cl = (const char BH64_CONSTANT *)ld;
+    // (all three requests of a quad are issued together and waited for once: left to itself the compiler issues the second
+    // half and the links only after the first half has arrived and its first node has passed the empty test -- two round
+    // trips per quad)
     auto load_quad = [&](int32_t first) {
         Quad64 q;
-        q.a = *(const w64_v16i BH64_CONSTANT *)(cg + (int64_t)first * 32);
-        q.b = *(const w64_v16i BH64_CONSTANT *)(cg + (int64_t)first * 32 + 64);
-        q.l = *(const w64_v8i BH64_CONSTANT *)(cl + (int64_t)first * 8);
+        const char BH64_CONSTANT *pn = cg + (int64_t)first * 32;
+        const char BH64_CONSTANT *pl = cl + (int64_t)first * 8;
+        asm volatile("s_load_dwordx16 %0, %3, 0x0\n\t"
+                     "s_load_dwordx16 %1, %3, 0x40\n\t"
+                     "s_load_dwordx8 %2, %4, 0x0\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(q.a), "=&s"(q.b), "=&s"(q.l)
+                     : "s"(pn), "s"(pl)
+                     : "memory");
         return q;
     };
 #pragma clang diagnostic pop
 
     int32_t v_base = 0, v_lo = 0, v_hi = 0, v_base2 = 0, v_lo2 = 0, v_hi2 = 0;   // register-lane stack, 128 entries
     int sp = 0;
-    bool h_free = false;                              // hand-off slot of the quad being evaluated
-    int32_t h_idx = -1;
+    int32_t h_idx = 0;                                // hand-off slot of the quad being evaluated: < 0 = free (a child index is > 0)
     uint64_t h_mask = 0;
 
     auto push = [&](int32_t child, uint64_t open) {
-        if (sp < kWave) {
+        if (!DEEP || sp < kWave) {
             v_base = bh64_writelane_i32(child, sp, v_base);
             v_lo = bh64_writelane_i32((int32_t)(uint32_t)open, sp, v_lo);
             v_hi = bh64_writelane_i32((int32_t)(uint32_t)(open >> 32), sp, v_hi);
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(kF64Block) void walk_f64_kernel(
     };
     auto pop = [&](int32_t &base, uint64_t &mask) {
         --sp;
-        if (sp < kWave) {
+        if (!DEEP || sp < kWave) {
             base = __builtin_amdgcn_readlane(v_base, sp);
             mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v_hi, sp) << 32) | (uint32_t)__builtin_amdgcn_readlane(v_lo, sp);
         } else {
@@ -125,7 +135,10 @@ __global__ __launch_bounds__(kF64Block) void walk_f64_kernel(
         // mass is a sum of the bodies' masses or +0.0
         {
             const int32_t mh = __double2hiint(m);
-            if (mh <= 0x3CD203AF && (mh < 0x3CD203AF || (uint32_t)__double2loint(m) <= 0x9EE75616u)) return;
+            if (__builtin_expect(mh <= 0x3CD203AF, 0)) {            // (nested: one s_cmp + branch on the usual path, no booleans in SGPR pairs)
+                if (mh < 0x3CD203AF) return;
+                if ((uint32_t)__double2loint(m) <= 0x9EE75616u) return;
+            }
         }
         const bool leaf = child < 0;                              // project.cu:623-626
         double dx, dy, d2, y, t, e;
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(kF64Block) void walk_f64_kernel(
         }
         if (STATS) { n_vis += __popcll(mask); ++n_wave; n_int += __popcll(takem); my_int += (uint32_t)((takem >> lane) & 1ull); }
         if (open != 0) {
-            if (h_free) { h_idx = child; h_mask = open; h_free = false; }
+            if (h_idx < 0) { h_idx = child; h_mask = open; }
             else push(child, open);
         }
     };
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(kF64Block) void walk_f64_kernel(
     {
         const NodeD r = gd[0];
         const LinkD k = ld[0];
-        h_free = true; h_idx = -1;
+        h_idx = -1;
         eval(r.cx, r.cy, r.m, r.size, k.child, k.occ, __ballot(valid));
     }
     int32_t na = h_idx;
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(kF64Block) void walk_f64_kernel(
         else break;
         const Quad64 q = load_quad(base);
         if (STATS) ++n_quad;
-        h_free = true; h_idx = -1;
+        h_idx = -1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             double cx, cy, m, size;
@@ -222,7 +235,6 @@ __global__ __launch_bounds__(kF64Block) void walk_f64_kernel(
         }
         na = h_idx; nam = h_mask;
     }
-    h_free = false;
 
     double2 np = p;
     if (valid) {
