@@ -90,7 +90,9 @@ __global__ __launch_bounds__(kF64Block) void walk_f64_kernel(
                      : "memory");
         return q;
     };
-#pragma clang diagnostic pop
+    // (Touching the next quad's three cache lines with scalar loads as soon as the hand-off child is known -- gfx9 has no
+    // scalar prefetch; the touches went to a register above the compiler's allocation -- made the walk SLOWER, 0.940 ->
+    // 0.985 ms: as in the fp32 loop, a scalar-memory request is the most expensive instruction there is.)
 
     int32_t v_base = 0, v_lo = 0, v_hi = 0, v_base2 = 0, v_lo2 = 0, v_hi2 = 0;   // register-lane stack, 128 entries
     int sp = 0;
