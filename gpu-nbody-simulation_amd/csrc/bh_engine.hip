@@ -279,9 +279,8 @@ int enqueue_build_t(bh_ctx *c)
 #endif
                           && c->sort_pack;
         // bucket sort (bh_sort.hpp): one counting pass by splitters from the previous build + one in-LDS sort per bucket
-        bool bucket = false;
-        if constexpr (!EXACT)
-            bucket = pack && c->hilbert && n >= 2 && n <= kBucketMaxNBig && (c->sort_bucket == 2 || (c->sort_bucket == 1 && c->samples_n == n));
+        // (exact modes and BH_HILBERT=0 too since round 3: the splitters only have to be sorted, whatever curve the keys follow)
+        const bool bucket = pack && n >= 2 && n <= kBucketMaxNBig && (c->sort_bucket == 2 || (c->sort_bucket == 1 && c->samples_n == n));
         const int nb = (n <= kBucketMaxN) ? kBuckets : kBucketsBig;
         // sample positions behind the splitters: two per bucket where the key workgroups run long enough to hide the
         // sample workgroups (256 buckets: above 262k bodies; 1,024 buckets: above 3M), one per bucket otherwise
@@ -293,10 +292,11 @@ int enqueue_build_t(bh_ctx *c)
             const unsigned nkb = blocks_for(n, kBlock);
             auto keys_launch = [&](auto hil, auto pk, auto fs) {
                 constexpr bool H = decltype(hil)::value, P = decltype(pk)::value, F = decltype(fs)::value;
-                const bool smp = H && P && bucket;                  // (the splitter workgroups exist in the packed Hilbert variant only)
+                const bool smp = P && bucket;                       // (the splitter workgroups go with the packed keys)
+                // samples: the previous build's sorted positions -- the fp32 walk's copy, or through the previous perm in the exact modes
                 hipLaunchKernelGGL((keys_kernel<Real2, H, P, F>), dim3(nkb + (smp ? ns / kWave : 0)), dim3(kBlock), 0, st, pos, c->box,
-                                   c->keys[0], c->vals[0], n, Dm, smp ? (const float2 *)c->spos : nullptr, c->splitters, nb, ns,
-                                   slots, c->ctr, smp ? c->bsum_sort : nullptr, smp ? nb : 0);
+                                   c->keys[0], c->vals[0], n, Dm, (smp && !EXACT) ? (const float2 *)c->spos : nullptr, c->splitters, nb, ns,
+                                   slots, c->ctr, smp ? c->bsum_sort : nullptr, smp ? nb : 0, (smp && EXACT) ? c->perm : nullptr);
             };
             using T = std::true_type; using Fz = std::false_type;
             // (exact mode and BH_HILBERT=0: child-index keys, packed all the same)
@@ -332,11 +332,20 @@ int enqueue_build_t(bh_ctx *c)
             constexpr int SI = (ITEMS == kItems ? kSortItems : ITEMS);
             auto pass = [&](auto bits_tag) {
                 constexpr int NBITS = decltype(bits_tag)::value;
-                hipLaunchKernelGGL((radix_hist<SI, NBITS, true>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->radix_counts, n,
-                                   0, (int)nbl, c->splitters, c->sort_dig, c->bsum_sort);
-                hipLaunchKernelGGL((radix_scatter_w<SI, NBITS, 1, true>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->vals[0],
-                                   c->keys[1], c->vals[1], c->radix_counts, c->bsum_sort, n, 0, (int)nbl, c->sort_dig,
-                                   c->bsum_sort + kBucketStartOffset);
+                if constexpr (EXACT) {                               // (state in caller order: the pass with its row scan, see radix_scatter_w)
+                    hipLaunchKernelGGL((radix_hist<SI, NBITS, true>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->radix_counts, n,
+                                       0, (int)nbl, c->splitters, c->sort_dig, nullptr);
+                    hipLaunchKernelGGL(radix_rowscan, dim3(1 << NBITS), dim3(kBlock), 0, st, c->radix_counts, c->bsum_sort, (int)nbl);
+                    hipLaunchKernelGGL((radix_scatter_w<SI, NBITS, 1, true, false>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->vals[0],
+                                       c->keys[1], c->vals[1], c->radix_counts, c->bsum_sort, n, 0, (int)nbl, c->sort_dig,
+                                       c->bsum_sort + kBucketStartOffset);
+                } else {
+                    hipLaunchKernelGGL((radix_hist<SI, NBITS, true>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->radix_counts, n,
+                                       0, (int)nbl, c->splitters, c->sort_dig, c->bsum_sort);
+                    hipLaunchKernelGGL((radix_scatter_w<SI, NBITS, 1, true>), dim3(nbl), dim3(kBlock), 0, st, c->keys[0], c->vals[0],
+                                       c->keys[1], c->vals[1], c->radix_counts, c->bsum_sort, n, 0, (int)nbl, c->sort_dig,
+                                       c->bsum_sort + kBucketStartOffset);
+                }
             };
             if (nb == kBuckets) pass(std::integral_constant<int, 8>{}); else pass(std::integral_constant<int, 10>{});
             hipLaunchKernelGGL(bucket_sort_kernel, dim3(nb), dim3(kBsThreads), 0, st, c->keys[1], c->keys[0], c->vals[0],
@@ -426,7 +435,7 @@ int enqueue_build_t(bh_ctx *c)
         };
         if (ITEMS == kItems && n <= (int64_t)1 << 21) scan_part(std::integral_constant<int, 4>{});
         else scan_part(std::integral_constant<int, ITEMS>{});
-        if constexpr (!EXACT) c->samples_n = n;                  // spos: this build's sorted positions
+        c->samples_n = n;                                        // spos (exact modes: perm): this build's sorted order
         if (c->time_groups) (void)hipEventRecord(c->ev_grp[2], st);
     } else {
         c->keys_sorted = c->keys[0];
@@ -501,6 +510,16 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
     // one pass.  It gives the thread axis of the reference's first scaling experiment (first_scaling_script.sh:
     // 17-36) a meaning on this hardware: n_threads = 1 is one workgroup at a time.
     const int64_t pass = c->cfg.n_threads > 0 ? ((int64_t)c->cfg.n_threads + kBlock - 1) / kBlock * kBlock : hi - lo;
+    // one launch over all bodies that integrates: the workgroups also fold their bounds into the slot records the
+    // next keys_kernel reduces (bh_bounds.hpp) -- that build then needs no bounds_final launch
+    const bool want_slots = want_partial && pass == hi - lo && part == 0 && !c->let_mode && !c->external_box && c->n >= 2;
+    double *slots = nullptr;
+    if (want_slots) {
+        if (c->slots_dirty)
+            hipLaunchKernelGGL(bounds_slots_reset, dim3(1), dim3(kWave), 0, c->stream, c->bslots);
+        slots = c->bslots; c->slots_dirty = true;
+    }
+    if (integrate) c->slots_valid = want_slots;
     if (c->exact && c->fast64) {
         if (stats && !c->body_counts) { int rc = dev_alloc(c, &c->body_counts, (size_t)std::max<int64_t>(c->cfg.capacity, 1)); if (rc) return rc; }
         for (int64_t plo = lo; plo < hi; plo += pass) {
@@ -510,7 +529,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
                 hipLaunchKernelGGL(kern, dim3(blocks_for(phi - plo, kF64Block)), dim3(kF64Block), 0, c->stream, c->gd, c->ld, c->perm,
                                    (double2 *)c->pos, (double2 *)c->vel, (const double *)c->mass,
                                    (double2 *)c->force, plo, phi, c->cfg.theta, c->cfg.G, c->cfg.dt,
-                                   integrate ? 1 : 0, c->ctr, pp, stats ? c->body_counts : nullptr);
+                                   integrate ? 1 : 0, c->ctr, pp, stats ? c->body_counts : nullptr, slots);
             };
             if (3 * c->Dm + 1 > kWave) {                         // (deeper than 21 levels: the two-tier stack)
                 if (c->compat) { if (stats) args(walk_f64_kernel<true, true, true>); else args(walk_f64_kernel<true, false, true>); }
@@ -530,7 +549,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
                 hipLaunchKernelGGL(kern, dim3(blocks_for(phi - plo, kBlock)), dim3(kBlock), 0, c->stream, c->gd, c->ld, c->perm,
                                    (double2 *)c->pos, (double2 *)c->vel, (const double *)c->mass,
                                    (double2 *)c->force, plo, phi, c->cfg.theta, c->cfg.G, c->cfg.dt,
-                                   integrate ? 1 : 0, c->ctr, pp);
+                                   integrate ? 1 : 0, c->ctr, pp, slots);
             };
             if (c->compat) { if (stats) args(walk_exact_kernel<true, true>); else args(walk_exact_kernel<true, false>); }
             else           { if (stats) args(walk_exact_kernel<false, true>); else args(walk_exact_kernel<false, false>); }
@@ -554,15 +573,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         a.group_cost = (lo == 0 && hi == c->n) ? c->group_cost : nullptr;
         a.bucket_consts = c->walk_consts;
         a.body_counts = nullptr;
-        // one launch over all bodies that integrates: the workgroups also fold their bounds into the slot records the
-        // next keys_kernel reduces (bh_bounds.hpp) -- that build then needs no bounds_final launch
-        const bool want_slots = want_partial && pass == hi - lo && part == 0 && !c->let_mode && !c->external_box && c->n >= 2;
-        if (want_slots) {
-            if (c->slots_dirty)
-                hipLaunchKernelGGL(bounds_slots_reset, dim3(1), dim3(kWave), 0, c->stream, c->bslots);
-            a.slots = c->bslots; c->slots_dirty = true;
-        }
-        if (integrate) c->slots_valid = want_slots;
+        a.slots = slots;
         if (stats) {
             if (!c->body_counts) { int rc = dev_alloc(c, &c->body_counts, (size_t)std::max<int64_t>(c->cfg.capacity, 1)); if (rc) return rc; }
             if (part != 2) BH_HIP(c, hipMemsetAsync(c->body_counts, 0, (size_t)std::max<int64_t>(c->n, 1) * sizeof(uint32_t), c->stream));
@@ -720,11 +731,11 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
       // (the bucket pass of launches above 1M bodies counts 1,024 buckets per tile; sized for the SMALLEST tile that
       // can reach it -- BH_BUILD_ITEMS=2 is honoured up to 4M bodies: 2 words per body, 32 MB at 4M -- ADVICE r2:
       // sized for kSortTile only, the 512-key tiles of that override wrote past the end between 1M and 4M bodies)
-      const size_t big = (!c->exact && cap > kBucketMaxN) ? (size_t)kBucketsBig * blocks_for(std::min<int64_t>(cap, kBucketMaxNBig), kBlock * kSmallItems) : 0;
+      const size_t big = (cap > kBucketMaxN) ? (size_t)kBucketsBig * blocks_for(std::min<int64_t>(cap, kBucketMaxNBig), kBlock * kSmallItems) : 0;
       A(&c->radix_counts, std::max<size_t>((size_t)(1 << kSortBits) * nbl, big));
       A(&c->bsum_sort, 2 * kBucketStartOffset);               // bucket totals, then bucket starts
       A(&c->splitters, kBucketsBig);
-      if (!c->exact) A(&c->sort_dig, (size_t)std::min<int64_t>(cap, kBucketMaxNBig) + 16);
+      A(&c->sort_dig, (size_t)std::min<int64_t>(cap, kBucketMaxNBig) + 16);
 #ifdef BHGPU_EXPERIMENTS
       c->os_status_words = (int64_t)kMaxPasses * nbl * kRadix;
       A(&c->os_status, c->os_status_words); A(&c->os_ghist, kMaxPasses * kRadix); A(&c->os_counter, kMaxPasses);

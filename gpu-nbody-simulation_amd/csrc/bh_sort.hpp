@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void radix_hist(const uint64_t *__restrict_
         // BUCKET: the bucket totals are summed here (keys_kernel zeroed them) and the scatter adds up the few rows it
         // needs itself -- the keys arrive almost in order, a tile meets one or two buckets -- so this pass has no
         // radix_rowscan launch between its two kernels
-        if (BUCKET && v) atomicAdd(&row_total[d], v);
+        if (BUCKET && row_total != nullptr && v) atomicAdd(&row_total[d], v);
     }
 }
 
@@ -186,7 +186,10 @@ __global__ __launch_bounds__(kBlock) void radix_hist(const uint64_t *__restrict_
 // PACK == 2: the last pass, which writes the plain key and the index to their own arrays for the tree build.
 constexpr int kPackShift = 40;
 constexpr uint64_t kPackKeyMask = (1ull << kPackShift) - 1;
-template <int ITEMS, int BITS = kRadixBits, int PACK = 0, bool BUCKET = false>
+// RAW (bucket pass only): `offs` holds the histogram's raw counts and the kernel adds up the rows it needs itself (no
+// radix_rowscan launch) -- for bodies that arrive almost in order.  The exact modes never re-order their state, a tile meets
+// as many buckets as it has room for, and the pass keeps its row scan (RAW = false: 29 us against 9 at N = 1M).
+template <int ITEMS, int BITS = kRadixBits, int PACK = 0, bool BUCKET = false, bool RAW = BUCKET>
 __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__restrict__ kin,
                                                            const uint32_t *__restrict__ vin,
                                                            uint64_t *__restrict__ kout,
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
         uint32_t all;
         uint32_t digit_base = block_exclusive_sum(tsum, sm, all);
         uint32_t lstart = block_exclusive_sum(csum, sm, all);
-        if (BUCKET) {
+        if (BUCKET && RAW) {
             // offs holds the histogram's raw counts: the keys of bucket d in the tiles before this one are the sum of row
             // d up to this tile.  The buckets this tile meets -- one or two in steady motion, a dozen when the bodies
             // have drifted for sixteen builds since the state was last put in order -- are listed, and the waves add up
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_w(const uint64_t *__rest
         for (int j = 0; j < DPT; ++j) {
             const int d = DPT * t + j;
             uint32_t before = 0;                                // keys of digit d in the tiles before this one
-            if (BUCKET) {
+            if (BUCKET && RAW) {
                 if (cnt[j]) {
                     const uint32_t np = s_np;
                     if (np <= (uint32_t)kRowsTogether) {

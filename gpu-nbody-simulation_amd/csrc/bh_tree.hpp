@@ -258,7 +258,8 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
                                                        const float2 *__restrict__ samples = nullptr,
                                                        uint64_t *__restrict__ splitters = nullptr, int nb = 0,
                                                        int ns = 0, double *slots = nullptr, TreeCounters *ctr = nullptr,
-                                                       uint32_t *__restrict__ zero_words = nullptr, int n_zero = 0)
+                                                       uint32_t *__restrict__ zero_words = nullptr, int n_zero = 0,
+                                                       const uint32_t *__restrict__ sample_perm = nullptr)
 {
     if (blockIdx.x == 0)                                         // (the bucket totals the histogram launch adds into: bh_sort.hpp)
         for (int k = threadIdx.x; k < n_zero; k += kBlock) zero_words[k] = 0u;
@@ -299,7 +300,8 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
         x0 = box_global[0]; x1 = box_global[1]; y0 = box_global[2]; y1 = box_global[3];
         bk4 = box_global[4]; bk5 = box_global[5]; bk6 = box_global[6]; bk7 = box_global[7];
     }
-    const int nsb = (samples != nullptr) ? ns / kWave : 0;      // extra workgroups in front of the key workgroups
+    // (sample_perm: the exact modes keep no sorted copy of the positions -- their samples are pos[previous build's perm[rank]])
+    const int nsb = (samples != nullptr || sample_perm != nullptr) ? ns / kWave : 0;      // extra workgroups in front of the key workgroups
     if ((int)blockIdx.x < nsb) {
         // ns sample positions -> keys -> ranks by counting -> every (ns / nb)-th in rank order is a splitter.
         // Every one of the ns / 64 sample workgroups forms all ns keys (cheap: one multiply per axis with the
@@ -320,7 +322,12 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
 #pragma unroll
         for (int k = 0; k < kMaxSplitSamples / kBlock; ++k) {
             const int j = t + k * kBlock;
-            qs[k] = (j < ns) ? samples[((int64_t)j * n) >> lg_ns] : float2{0.f, 0.f};
+            qs[k] = float2{0.f, 0.f};
+            if (j < ns) {
+                const int64_t rk = ((int64_t)j * n) >> lg_ns;
+                if (sample_perm != nullptr) { const Real2 pp = pos[sample_perm[rk]]; qs[k] = float2{(float)pp.x, (float)pp.y}; }
+                else qs[k] = samples[rk];
+            }
         }
 #pragma unroll
         for (int k = 0; k < kMaxSplitSamples / kBlock; ++k) {

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
     const NodeD *__restrict__ gd, const LinkD *__restrict__ ld, const uint32_t *__restrict__ perm,
     double2 *__restrict__ pos, double2 *__restrict__ vel, const double *__restrict__ mass,
     double2 *__restrict__ force_out, int64_t lo, int64_t hi, double theta, double G, double dt,
-    int integrate, TreeCounters *ctr, double *__restrict__ partial)
+    int integrate, TreeCounters *ctr, double *__restrict__ partial, double *slots)
 {
     __shared__ int32_t s_quad[kWavesPerBlock][kExactLevels];
     __shared__ int32_t s_next[kWavesPerBlock][kExactLevels];
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
         }
     }
     // min/max of the new positions per workgroup: the next step's root box needs no body pass
-    if (partial) block_bounds_to_partial(valid, np.x, np.y, partial + 4 * (size_t)blockIdx.x);
+    if (partial) block_bounds_to_partial(valid, np.x, np.y, partial + 4 * (size_t)blockIdx.x, slots);
     if (STATS) {
         // one atomic per wave
         if (lane == 0) {

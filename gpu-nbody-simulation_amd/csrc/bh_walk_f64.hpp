@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kF64Block) void walk_f64_kernel(
     const NodeD *__restrict__ gd, const LinkD *__restrict__ ld, const uint32_t *__restrict__ perm,
     double2 *__restrict__ pos, double2 *__restrict__ vel, const double *__restrict__ mass,
     double2 *__restrict__ force_out, int64_t lo, int64_t hi, double theta, double G, double dt,
-    int integrate, TreeCounters *ctr, double *__restrict__ partial, uint32_t *__restrict__ body_counts)
+    int integrate, TreeCounters *ctr, double *__restrict__ partial, uint32_t *__restrict__ body_counts, double *slots)
 {
     if (ctr->overflow) return;
     const int lane = lane_id();
@@ -260,9 +260,10 @@ __global__ __launch_bounds__(kF64Block) void walk_f64_kernel(
             if (lane == 0) {
                 double *o = partial + 4 * (size_t)blockIdx.x;
                 o[0] = xlo; o[1] = xhi; o[2] = ylo; o[3] = yhi;
+                if (slots) bounds_to_slot(xlo, xhi, ylo, yhi, slots, blockIdx.x);
             }
         } else {
-            block_bounds_to_partial(valid, np.x, np.y, partial + 4 * (size_t)blockIdx.x);
+            block_bounds_to_partial(valid, np.x, np.y, partial + 4 * (size_t)blockIdx.x, slots);
         }
     }
     if (STATS && lane == 0) {
