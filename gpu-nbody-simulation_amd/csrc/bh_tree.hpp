@@ -628,8 +628,15 @@ __global__ __launch_bounds__(kBlock) void nodes_exact_kernel(
         if (t == 0) ctr->overflow = 1;
         return;
     }
-    if (t >= (int64_t)total) return;
+    // (the workgroup's 1,024 nodes are contiguous in memory: they are assembled in LDS and written out with coalesced
+    // stores -- field by field from the owning lanes they were 24 stores per cell, each spread over 64 cache lines)
+    __shared__ double s_nd[kBlock * 16];                         // per thread: four nodes x {cx, cy, m, size}
+    __shared__ int32_t s_ln[kBlock * 8];                         // per thread: four links x {child, occ}
+    const int64_t r_block = (int64_t)blockIdx.x * kBlock;
+    if (r_block >= (int64_t)total) return;                       // uniform per workgroup
+    const bool active = t < (int64_t)total;
     const uint32_t r = (uint32_t)t;
+    if (active) {
     const int64_t i = (int64_t)cell_first[r];
     const uint64_t key = keys[i];
     const int Lp = (i == 0) ? -1 : shared_levels(keys[i - 1], key, Dm);
@@ -643,11 +650,62 @@ __global__ __launch_bounds__(kBlock) void nodes_exact_kernel(
 
     const int sh = 2 * (Dm - d);                     // bits below the depth-d prefix
     const uint64_t pfx = (d == 0) ? 0ull : (key >> sh);
-    const int64_t e = (d == 0) ? n : cell_end(keys, i, n, sh, pfx);
     const int shc = sh - 2;
+    int64_t e = n;
     int64_t b[5];
+    bool settled = false;
+    if (d != 0) {
+        // Most cells hold a handful of bodies: the next eight keys, read in ONE round of independent loads, settle the end
+        // and the three child boundaries of every cell of at most eight bodies (as in nodes_fast_kernel); the searches
+        // below are chains of dependent loads, four of them one after the other.
+        const uint64_t cell_hi = (pfx + 1) << sh;                // keys are sorted: outside the cell <=> key >= cell_hi
+        uint64_t nk[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) nk[j] = (i + 1 + j < n) ? keys[i + 1 + j] : ~0ull;
+        int inside = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) inside += (nk[j] < cell_hi) ? 1 : 0;
+        if (inside < 8) {
+            e = i + 1 + inside;
+            int below1 = 0, below2 = 0, below3 = 0;              // bodies of the cell in children < 1, < 2, < 3
+            {
+                const uint32_t dg = (uint32_t)(key >> shc) & 3u;
+                below1 += dg < 1u; below2 += dg < 2u; below3 += dg < 3u;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t dg = (j < inside) ? (uint32_t)(nk[j] >> shc) & 3u : 3u;
+                below1 += dg < 1u; below2 += dg < 2u; below3 += dg < 3u;
+            }
+            b[1] = i + below1; b[2] = i + below2; b[3] = i + below3;
+            settled = true;
+        } else {
+            e = cell_end(keys, i, n, sh, pfx);
+        }
+    }
     b[0] = i; b[4] = e;
-    for (int c = 1; c < 4; ++c) b[c] = lower_bound_prefix(keys, b[c - 1], e, shc, (pfx << 2) | (uint64_t)c);
+    if (!settled) {
+        // the three boundaries in lock-step: three independent loads per round instead of three searches one after the
+        // other (this kernel lasts as long as its longest chain of dependent loads -- the few cells next to the root,
+        // whose searches span the whole array: ~60 loads in a row before, ~20 now)
+        int64_t lo3[3] = {i, i, i}, hi3[3] = {e, e, e};
+        while ((lo3[0] < hi3[0]) | (lo3[1] < hi3[1]) | (lo3[2] < hi3[2])) {
+            int64_t mid[3];
+            uint64_t km[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                mid[c] = (lo3[c] + hi3[c]) >> 1;
+                km[c] = (lo3[c] < hi3[c]) ? keys[mid[c]] : 0ull;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (lo3[c] < hi3[c]) {
+                    if ((km[c] >> shc) < ((pfx << 2) | (uint64_t)(c + 1))) lo3[c] = mid[c] + 1; else hi3[c] = mid[c];
+                }
+            }
+        }
+        b[1] = lo3[0]; b[2] = lo3[1]; b[3] = lo3[2];
+    }
 
     const double mx = (x0 + x1) / 2.0, my = (y0 + y1) / 2.0;
     const int32_t quad = 1 + 4 * (int32_t)r;     // id of child 0
@@ -660,12 +718,36 @@ __global__ __launch_bounds__(kBlock) void nodes_exact_kernel(
     }
     cell_depth[r] = d;
     uint32_t n_sub = 0;                            // subdivided children: what the bottom-up pass waits for
+    // what the four children need from memory, all of it requested before any of it is used (perm first, then the
+    // bodies / the keys and ranks behind it): two rounds of independent loads instead of a chain per child
+    int64_t bc4[4], nc4[4];
+    uint32_t bi1[4], offc[4];
+    uint64_t kprev[4], kcur[4];
+    bool sub4[4], one4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bc4[c] = b[c]; nc4[c] = b[c + 1] - b[c];
+        sub4[c] = nc4[c] > 1 && d + 1 < Dm;
+        one4[c] = nc4[c] == 1 && d + 1 < Dm;
+        bi1[c] = one4[c] ? perm[bc4[c]] : 0u;
+        offc[c] = sub4[c] ? off[bc4[c]] : 0u;
+        kcur[c] = sub4[c] ? keys[bc4[c]] : 0ull;
+        kprev[c] = (sub4[c] && bc4[c] > 0) ? keys[bc4[c] - 1] : 0ull;
+    }
+    double m1[4];
+    double2 p1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        m1[c] = one4[c] ? mass[bi1[c]] : 0.0;
+        p1[c] = one4[c] ? pos[bi1[c]] : double2{0.0, 0.0};
+    }
+#pragma unroll
     for (int c = 0; c < 4; ++c) {
         const double cx0 = (c & 1) ? mx : x0, cx1 = (c & 1) ? x1 : mx;
         const double cy0 = (c & 2) ? my : y0, cy1 = (c & 2) ? y1 : my;
         const double ex = cx1 - cx0, ey = cy1 - cy0;
         const double size = (ex > ey) ? ex : ey;
-        const int64_t bc = b[c], nc = b[c + 1] - b[c];
+        const int64_t bc = bc4[c], nc = nc4[c];
         const int32_t node = quad + c;
         double m = 0.0, cx = 0.0, cy = 0.0;
         int32_t child = -1, occ = -1;
@@ -683,21 +765,33 @@ __global__ __launch_bounds__(kBlock) void nodes_exact_kernel(
             occ = (nc == 1) ? (-(int32_t)perm[bc] - 2) : -1;
         } else if (nc == 1) {
             // single body in an undivided cell, project.cu:398-406
-            const uint32_t bi = perm[bc];
-            m = mass[bi]; cx = pos[bi].x; cy = pos[bi].y;
-            occ = (int32_t)bi;
+            m = m1[c]; cx = p1[c].x; cy = p1[c].y;
+            occ = (int32_t)bi1[c];
         } else {
             // subdivided cell: its rank follows from its first body and depth
-            const int Lpc = (bc == 0) ? -1 : shared_levels(keys[bc - 1], keys[bc], Dm);
-            const uint32_t rc = off[bc] + (uint32_t)((d + 1) - (Lpc + 1));
+            const int Lpc = (bc == 0) ? -1 : shared_levels(kprev[c], kcur[c], Dm);
+            const uint32_t rc = offc[c] + (uint32_t)((d + 1) - (Lpc + 1));
             child = 1 + 4 * (int32_t)rc;
             self_node[rc] = node;
             ++n_sub;
         }
-        gd[node] = NodeD{cx, cy, m, size};
-        ld[node] = LinkD{child, occ};
+        double *sn = s_nd + threadIdx.x * 16 + 4 * c;
+        sn[0] = cx; sn[1] = cy; sn[2] = m; sn[3] = size;
+        s_ln[threadIdx.x * 8 + 2 * c] = child; s_ln[threadIdx.x * 8 + 2 * c + 1] = occ;
     }
     pending[r] = n_sub;
+    }   // active
+    __syncthreads();
+    {
+        const int64_t left = (int64_t)total - r_block;
+        const int cells = (left < kBlock) ? (int)left : kBlock;
+        double2 *dn = reinterpret_cast<double2 *>(gd + 1 + 4 * r_block);           // 32-byte aligned: node 1 + 4 r
+        const double2 *sn = reinterpret_cast<const double2 *>(s_nd);
+        for (int k = threadIdx.x; k < cells * 8; k += kBlock) dn[k] = sn[k];
+        int2 *dl = reinterpret_cast<int2 *>(ld + 1 + 4 * r_block);
+        const int2 *sl = reinterpret_cast<const int2 *>(s_ln);
+        for (int k = threadIdx.x; k < cells * 4; k += kBlock) dl[k] = sl[k];
+    }
 }
 
 // ---- fp32 nodes kernel ------------------------------------------------------------------------------
