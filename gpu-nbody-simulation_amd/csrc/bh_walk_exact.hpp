@@ -18,6 +18,7 @@
 namespace bh {
 
 constexpr int kExactLevels = 34;   // max_depth <= 32 -> at most 32 stacked levels
+extern "C" __device__ int exact_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 
 template <bool COMPAT, bool STATS>
 __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
@@ -26,12 +27,13 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
     double2 *__restrict__ force_out, int64_t lo, int64_t hi, double theta, double G, double dt,
     int integrate, TreeCounters *ctr, double *__restrict__ partial, double *slots)
 {
-    __shared__ int32_t s_quad[kWavesPerBlock][kExactLevels];
-    __shared__ int32_t s_next[kWavesPerBlock][kExactLevels];
-    __shared__ uint64_t s_mask[kWavesPerBlock][kExactLevels];
+    // The traversal stack -- one entry per tree level: {quad of the level, next child to visit, lanes that walk it} -- lives
+    // in four VGPRs, entry k in lane k (round 3; it was three LDS arrays written by lane 0 and read back through
+    // v_readfirstlane: a round trip through LDS on every visited node of a walk that is one long dependent chain).
+    int32_t v_quad = 0, v_next = 0, v_mlo = 0, v_mhi = 0;
 
     if (ctr->overflow) return;
-    const int w = wave_id(), lane = lane_id();
+    const int lane = lane_id();
     const int64_t s = lo + (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool valid = s < hi;
     const int64_t body = valid ? (int64_t)perm[s] : -1;
@@ -88,28 +90,28 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
         return __ballot(mine && !accept);
     };
 
+    auto push = [&](int at, int32_t quad, uint64_t mask) {
+        v_quad = exact_writelane_i32(quad, at, v_quad);
+        v_next = exact_writelane_i32(3, at, v_next);
+        v_mlo = exact_writelane_i32((int32_t)(uint32_t)mask, at, v_mlo);
+        v_mhi = exact_writelane_i32((int32_t)(uint32_t)(mask >> 32), at, v_mhi);
+    };
     int sp = -1;
     {
         int32_t child;
         const uint64_t open = visit(0, __ballot(valid), child);
-        if (open != 0 && child >= 0) {
-            sp = 0;
-            if (lane == 0) { s_quad[w][0] = child; s_next[w][0] = 3; s_mask[w][0] = open; }
-        }
+        if (open != 0 && child >= 0) { sp = 0; push(0, child, open); }
     }
     while (sp >= 0) {
-        // wave-uniform state (every lane reads the same LDS words)
-        const int32_t quad = __builtin_amdgcn_readfirstlane(s_quad[w][sp]);
-        const int32_t c = __builtin_amdgcn_readfirstlane(s_next[w][sp]);
+        const int32_t c = __builtin_amdgcn_readlane(v_next, sp);
         if (c < 0) { --sp; continue; }
-        const uint64_t live = s_mask[w][sp];
-        if (lane == 0) s_next[w][sp] = c - 1;
+        const int32_t quad = __builtin_amdgcn_readlane(v_quad, sp);
+        const uint64_t live = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v_mhi, sp) << 32) |
+                              (uint32_t)__builtin_amdgcn_readlane(v_mlo, sp);
+        v_next = exact_writelane_i32(c - 1, sp, v_next);
         int32_t child;
         const uint64_t open = visit(quad + c, live, child);
-        if (open != 0 && child >= 0 && sp + 1 < kExactLevels) {
-            ++sp;
-            if (lane == 0) { s_quad[w][sp] = child; s_next[w][sp] = 3; s_mask[w][sp] = open; }
-        }
+        if (open != 0 && child >= 0 && sp + 1 < kExactLevels) { ++sp; push(sp, child, open); }
     }
 
     double2 np = p;
