@@ -49,7 +49,7 @@ def worker(a):
                     e.step(2)
                     res.append((acc,) + e.download())
             ok = ok and all(np.array_equal(x, y) for x, y in zip(*res)) and np.isfinite(res[0][0]).all()
-    out["bitwise_equal_portable"] = ok
+    out["bitwise_equal_portable"] = bool(ok)
     # ---- timing
     for kind, n in [("plummer", a.n)] + ([("uniform", a.n), ("plummer", 131072)] if a.more else []):
         m, p, v = cached(kind, n)
