@@ -117,7 +117,7 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
 // pair).  An iteration that starts with at most 56 entries touches only the first register triple and runs a
 // copy of the loop without the "which triple?" tests.
 // Hazards handled by instruction order (the assembler inserts no wait states into inline assembly): the consumer
-// of v_rsq_f32 is separated from it by the scalar push logic; the consumer of v_pk_add_f32 by the empty-cell test;
+// of v_rsq_f32 is separated from it by the scalar push logic; the consumer of v_pk_add_f32 by an s_nop;
 // m0 is written at least one instruction before a lane select uses it.
 // Fixed SGPRs: s[24:43] quad A, s[44:45] its lane mask, s[46:47] B's mask (0: no B in flight), s[48:67] quad B,
 // s68 / s69 A's quad index and byte offset and, once the loads are issued, the hand-off pair (also the open-mask
@@ -142,12 +142,15 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
     "v_fmac_f32_e32 v28, v24, v22\n"                                                                \
     "v_fmac_f32_e32 v29, v24, v23\n"                                                                \
     "s_mov_b64 exec, " MASK "\n"
-// v_pk_add_f32 sits ABOVE the empty-cell test: the two scalar instructions of the test are the wait state a packed
-// result needs before it is read (an empty child wastes those 4 cycles)
+// The empty-cell test comes FIRST (end of round 3): one child in six of an evaluated quad is empty (17.7 M child slots,
+// 14.7 M non-empty per launch at N = 1M), and the loop is made of vector cycles -- a v_pk_add_f32 per empty child was
+// 1.6 % of them.  The wait state a packed result needs before it is read is an s_nop now (it sat in the two scalar
+// instructions of the test): scalar issue, which other waves' vector instructions overlap.  Walk 0.3130 -> 0.3088 ms.
 #define BH_CHILD_HEAD(XY, MS, TS, MASK, SPAIR, TAG)                                                 \
-    "v_pk_add_f32 v[22:23], " XY ", v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n"                           \
     "s_cmp_eq_u32 " MS ", 0\n"                                                                      \
     "s_cbranch_scc1 Lnext" TAG "_%=\n"                                                              \
+    "v_pk_add_f32 v[22:23], " XY ", v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n"                           \
+    "s_nop 0\n"                                                                                     \
     "v_mul_f32_e32 v24, v23, v23\n"                                                                 \
     "v_fmac_f32_e32 v24, v22, v22\n"                                                                \
     "v_cmpx_lt_f32_e32 vcc, " TS ", v24\n"                                                          \
