@@ -44,6 +44,18 @@ NODE_BYTES = 20         # fp32 node: one quarter of the 80-byte sibling-quad rec
 VALU_CYCLES_PER_CHILD = 4.2 + 2.2 + 2.2 + 4.3 + 8.3 + 4.2 + 2.2 + 2.2 + 2.2 + 2.2
 VALU_CYCLES_PER_QUAD = 2.5 * 4.1 + 2.5 * 4.2
 N_SIMDS, SHADER_CLOCK_HZ = 1024, 2.4e9
+# BH_PRECISION_F64 walk (csrc/bh_walk_f64.hpp, walk64_asm).  Cycles of one SIMD per wave-instruction with 8 resident waves,
+# scripts/calib/f64_issue_calib.hip: any fp64 VALU instruction 5.3, v_rsq_f64 17, v_cmpx 4.3-5.3, lane moves 4.1-4.2.
+# Per evaluated node: dx, dy, d2 (4 x fp64) + the compare; per node some lane accepts: v_rsq_f64 + 4 (Newton) + 5 (weight)
+# + 2 (sums); per quad: on average 2.5 lane reads + 2.5 lane writes of the stack like the fp32 loop (the first opened child
+# stays in scalar registers).  Algorithmic bytes: 40 B per evaluated node (32-byte node + 8-byte link) + 92 B per body
+# (position 16, index 4, mass 8, velocity r/w 32, position w 16, force w 16).
+F64_CYCLES_PER_NODE = 4 * 5.3 + 5.3
+F64_CYCLES_PER_ACCEPTED = 17.0 + 11 * 5.3
+F64_CYCLES_PER_QUAD = 2.5 * 4.1 + 2.5 * 4.2
+F64_NODE_BYTES, F64_BODY_BYTES = 40, 92
+# algorithmic bytes of one whole step per body, fp32 state -- fixed pipeline ~270 B + walk 12 + 20 U64 + 8
+SURVEY_PIPELINE_BYTES, SURVEY_WALK_FIXED_BYTES = 270, 20
 
 
 def parse():
@@ -83,7 +95,28 @@ def parse():
                     help="comma-separated BASELINE configurations for the other_configs leg ('' = none)")
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="bodies walked by the CPU baseline (0 = all, i.e. one full step)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing check: parse, (spawn,) join the process group, all-reduce the ranks, print what a real "
+                         "run would be launched as -- no device is touched (tests/test_bench_launch_cpu.py)")
     return ap.parse_args()
+
+
+def spawn_ranks(a, argv):
+    """`bench.py --gpus N` started WITHOUT torch.distributed.run (no RANK in the environment): start the N ranks ourselves --
+    a child `python -m torch.distributed.run ... bench.py <the same arguments>` -- relay its output and leave with its code.
+    (this used to print a note on stderr and measure ONE GPU.)  Called before torch is imported: no device has
+    been touched by this process, and the children are fresh processes, not an exec of this one."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: --gpus %d without a launcher; starting the ranks: %s" % (a.gpus, " ".join(cmd)), file=sys.stderr)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(mass, pos, theta, sample):
@@ -165,6 +198,26 @@ def rank_churn(p0, p1, depth=16):
             "median_abs_rank_shift": float(np.median(np.abs(r1 - r0)))}
 
 
+def _single_gpu_file(a, n):
+    import tempfile
+    return os.path.join(tempfile.gettempdir(), f"bhgpu_bench_1gpu_{_digest()}_{a.init}_{n}_{a.theta}_{a.precision}.json")
+
+
+def single_gpu_record(a, n, write=None):
+    """The `--gpus 1` leg of the same library and workload, kept between the runs of one scaling series (the driver runs
+    N = 1, 2, 4, 8 back to back on one node): written by a one-GPU run, read by the others.  None if there is none."""
+    f = _single_gpu_file(a, n)
+    try:
+        if write is not None:
+            with open(f, "w") as fh:
+                json.dump(write, fh)
+            return write
+        with open(f) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
+
+
 def spread(x):
     """p50 / min / max of a per-step series (HIP events per step, bh_step_times)."""
     x = np.asarray(x, dtype=np.float64)
@@ -198,12 +251,43 @@ def timed_leg(G, cfg, mass, pos, vel, steps, warmup, want_state=True):
     n = len(mass)
     return {"value": n * steps / dt, "unit": "body-steps/s", "ms_per_step": dt / steps * 1e3, "build_ms": st.build_ms,
             "walk_ms": st.walk_ms, "keys_ms": st.keys_ms, "sort_ms": st.sort_ms, "scan_ms": st.scan_ms,
-            "nodes_ms": st.nodes_ms, "per_step": sp}, p0, p1
+            "nodes_ms": st.nodes_ms, "build_bytes_per_body": st.build_bytes / max(n, 1), "per_step": sp}, p0, p1
 
 
-def walk_roofline(G, cfg, mass, pos, vel, walk_ms, stats_flag):
+def committed_traffic(tag):
+    """HBM bytes per walk launch from the committed rocprofv3 PMC passes of the same command (counters cannot be read from
+    inside the process): profiles/latest_walk_traffic[_<tag>].json, written by scripts/summarize_profile.py, which stamps
+    the digest of the device sources -- a profile of OTHER kernels than the ones running is not reported."""
+    name = "latest_walk_traffic.json" if tag == "C3" else f"latest_walk_traffic_{tag}.json"
+    digest = _digest()
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            tj = json.load(fh)
+    except (OSError, ValueError):
+        return {"traffic": None, "traffic_source": None, "traffic_source_digest": None, "source_digest": digest}
+    ok = tj.get("source_digest") == digest
+    return {"traffic": tj.get("traffic_bytes") if ok else None, "traffic_source": tj.get("source") if ok else None,
+            "traffic_source_digest": tj.get("source_digest"), "source_digest": digest}
+
+
+def step_roofline(ms_per_step, n, u64, build_bytes_per_body=None, kind="f32"):
+    """The WHOLE step against the HBM peak: algorithmic bytes per body-step x N / time per step.
+    fp32 state: SURVEY's figure, ~270 B of fixed pipeline + 12 + 8 + 20 U64 of walk with this leg's measured U64
+    (0.56 KB at C2, 0.60 KB at C3).  fp64 legs: the engine's own per-kernel count for the build (bh_stats_t.build_bytes)
+    + 92 + 40 U64."""
+    if kind == "f32":
+        per_body = SURVEY_PIPELINE_BYTES + SURVEY_WALK_FIXED_BYTES + NODE_BYTES * u64
+    else:
+        per_body = (build_bytes_per_body or 0.0) + F64_BODY_BYTES + F64_NODE_BYTES * u64
+    ach = per_body * n / (ms_per_step * 1e-3) / 1e9
+    return {"bound": "hbm", "bytes_per_body_step": per_body, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS}
+
+
+def walk_roofline(G, cfg, mass, pos, vel, walk_ms, stats_flag, kind="f32"):
     """Algorithmic bytes of ONE walk + integrate launch on this state (counting variant of the kernel, untimed)
-    over the measured kernel time: 44 B per body + 20 B per node a wavefront evaluates."""
+    over the measured kernel time (DESIGN.md section 6).  kind f32: 44 B per body + 20 B per node a wavefront evaluates;
+    f64 / exact (the fp64 modes: 32-byte node + 8-byte link): 92 B per body + 40 B per node."""
     import dataclasses
     c2 = dataclasses.replace(cfg, flags=cfg.flags | stats_flag)
     with G.BarnesHutEngine(c2) as se:
@@ -211,11 +295,27 @@ def walk_roofline(G, cfg, mass, pos, vel, walk_ms, stats_flag):
         se.compute_forces()
         ss = se.stats()
     n = len(mass)
-    b = n * 44 + ss.wave_nodes * NODE_BYTES
+    body_b, node_b = (44, NODE_BYTES) if kind == "f32" else (F64_BODY_BYTES, F64_NODE_BYTES)
+    b = n * body_b + ss.wave_nodes * node_b
     ach = b / (walk_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "kernel_ms": walk_ms, "algorithmic_bytes_per_launch": b, "u64_nodes_per_body": ss.wave_nodes / n,
-            "interactions_per_body": ss.interactions / n, "n_nodes": ss.n_nodes}
+    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "kernel_ms": walk_ms, "algorithmic_bytes_per_launch": b, "u64_nodes_per_body": ss.wave_nodes / n,
+         "interactions_per_body": ss.interactions / n, "n_nodes": ss.n_nodes}
+    simd_cycles = N_SIMDS * walk_ms * 1e-3 * SHADER_CLOCK_HZ
+    if kind == "f32" and ss.wave_quads:
+        valu = ss.wave_nodes * VALU_CYCLES_PER_CHILD + ss.wave_quads * VALU_CYCLES_PER_QUAD
+        r["issue_frac"] = valu / simd_cycles
+    elif kind == "f64" and ss.wave_quads:
+        valu = (ss.wave_nodes * F64_CYCLES_PER_NODE + ss.wave_accepts * F64_CYCLES_PER_ACCEPTED
+                + ss.wave_quads * F64_CYCLES_PER_QUAD)
+        r["issue_frac"] = valu / simd_cycles
+        r["issue"] = {"valu_cycles_per_launch": valu, "simd_cycles_per_launch": simd_cycles, "nodes_per_launch": ss.wave_nodes,
+                      "accepted_nodes_per_launch": ss.wave_accepts, "quads_per_launch": ss.wave_quads,
+                      "cycles_per_node": F64_CYCLES_PER_NODE, "cycles_per_accepted_node": F64_CYCLES_PER_ACCEPTED,
+                      "cycles_per_quad": F64_CYCLES_PER_QUAD, "clock_hz_assumed": SHADER_CLOCK_HZ}
+    elif kind == "exact":
+        r["issue_frac"] = None      # (IEEE sqrt and three divisions per interaction, compiler-scheduled: no calibrated model)
+    return r
 
 
 def other_configs(G, IC, local, seed, stats_flag, which):
@@ -233,6 +333,8 @@ def other_configs(G, IC, local, seed, stats_flag, which):
         cfg = G.BhConfig(capacity=n, theta=theta, max_depth=21, precision=prec, reference_compat=False, device=local)
         leg, _, _ = timed_leg(G, cfg, m, p, v, steps, warm, want_state=False)
         leg["roofline"] = walk_roofline(G, cfg, m, p, v, leg["walk_ms"], stats_flag)
+        leg["roofline"].update(committed_traffic(tag))
+        leg["step_roofline"] = step_roofline(leg["ms_per_step"], n, leg["roofline"]["u64_nodes_per_body"])
         leg["minteractions_per_s"] = leg["roofline"]["interactions_per_body"] * leg["value"] / 1e6
         out[tag] = {"workload": f"{kind}_N{n}_theta{theta}_{'mixed' if prec == G.Precision.MIXED else 'f32'}", "steps": steps,
                     "warmup": warm, **leg}
@@ -242,6 +344,13 @@ def other_configs(G, IC, local, seed, stats_flag, which):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(a, sys.argv[1:]))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: launch it as\n"
+                         f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 "
+                         f"--master-port P bench.py --gpus {a.gpus} ...\n(or plainly `python bench.py --gpus {a.gpus}`, "
+                         f"which starts the ranks itself)")
     import torch
     import torch.distributed as dist
     import gpu_nbody_simulation_amd as G
@@ -250,14 +359,23 @@ def main():
                                                       partition_orb)
     from gpu_nbody_simulation_amd.engine import FLAG_LDS_STACK, FLAG_WALK_STATS
 
-    rank, local, world = init_process_group_from_env(a.backend)
+    rank, local, world = init_process_group_from_env("gloo" if a.dry_run else a.backend)
+    if a.dry_run:
+        t = torch.tensor([rank], dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "sum_of_ranks": int(t.item()), "gpus_arg": a.gpus,
+                              "steps": a.steps, "warmup": a.warmup, "decomposition": a.decomposition,
+                              "launched_by": "torch.distributed.run" if "RANK" in os.environ else "direct"}))
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if a.force_sharded and world == 1 and not dist.is_initialized() and "RANK" in os.environ:
         dist.init_process_group(backend="nccl", rank=0, world_size=1)
     if world != a.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        a.gpus = world
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the process group has {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     if "BHGPU_REHEARSE_ON_DEVICE" in os.environ:
@@ -359,9 +477,19 @@ def main():
                   "max_over_ranks": {k: float(x) for k, x in zip(keys, tmax)},
                   "mean_over_ranks": {k: float(x) / world for k, x in zip(keys, tsum)}}
         largest = stepper.check()                    # raises if a LET outgrew its block: run invalid
+        cnt = torch.zeros(world, dtype=torch.int64)
+        cnt[rank] = int(eng.n)
+        if world > 1:
+            cnt = cnt.to(dev) if a.backend == "nccl" else cnt
+            dist.all_reduce(cnt)
+            cnt = cnt.cpu()
         let_info = {"let_cap_quads": cap, "largest_let_quads": largest,
                     "all_to_all_bytes_per_rank_per_step": cap * 80 * (world - 1),
-                    "bodies_on_rank0": int(bodies_here), "bodies_per_rank_balanced": n / world}
+                    "bodies_on_rank0": int(bodies_here), "bodies_per_rank_balanced": n / world,
+                    # what a scaling record needs to explain itself: the shares at the end of the run, and the one-GPU
+                    # time of THIS library on THIS workload if a `--gpus 1` run left it on this machine (same digest)
+                    "efficiency_inputs": {"bodies_per_rank_min": int(cnt.min()), "bodies_per_rank_max": int(cnt.max()),
+                                          "single_gpu": single_gpu_record(a, n)}}
 
     st = eng.stats()                                 # HIP events recorded inside the timed region
     walk_ms = st.walk_ms if not sharded else None
@@ -452,21 +580,12 @@ def main():
         roof = None
         if walk_ms:
             ach = walk_bytes / (walk_ms * 1e-3) / 1e9
-            # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-            # (profiles/latest_walk_traffic.json, written by scripts/summarize_profile.py; counters
-            # cannot be read from inside the process)
-            traffic, tsrc, tdig = None, None, None
-            from gpu_nbody_simulation_amd.build import source_digest
-            digest = source_digest()
-            try:
-                with open(os.path.join(ROOT, "profiles", "latest_walk_traffic.json")) as fh:
-                    tj = json.load(fh)
-                tdig = tj.get("source_digest")
-                # only a profile of THESE kernels on THIS workload counts
-                if n == 1 << 20 and a.init == "plummer" and tdig == digest:
-                    traffic, tsrc = tj["traffic_bytes"], tj["source"]
-            except (OSError, KeyError, ValueError):
-                pass
+            # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command: only a profile of
+            # THESE kernels on THIS workload counts
+            ct = committed_traffic("C3")
+            if not (n == 1 << 20 and a.init == "plummer"):
+                ct.update(traffic=None, traffic_source=None)
+            traffic, tsrc, tdig, digest = ct["traffic"], ct["traffic_source"], ct["traffic_source_digest"], ct["source_digest"]
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                     "traffic_source_digest": tdig, "source_digest": digest,
@@ -480,7 +599,8 @@ def main():
                 roof["issue_frac"] = valu / (N_SIMDS * walk_ms * 1e-3 * SHADER_CLOCK_HZ)
                 roof["issue"] = {"valu_cycles_per_launch": valu, "simd_cycles_per_launch": N_SIMDS * walk_ms * 1e-3 * SHADER_CLOCK_HZ,
                                  "quads_per_launch": wq, "children_per_launch": ss.wave_nodes,
-                                 "cycles_per_child": VALU_CYCLES_PER_CHILD, "cycles_per_quad": VALU_CYCLES_PER_QUAD}
+                                 "cycles_per_child": VALU_CYCLES_PER_CHILD, "cycles_per_quad": VALU_CYCLES_PER_QUAD,
+                                 "clock_hz_assumed": SHADER_CLOCK_HZ}
         out = {
             "metric": "body-steps/sec", "value": value, "unit": "body-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -498,9 +618,12 @@ def main():
             "build_groups_ms": {"keys": st.keys_ms, "sort": st.sort_ms, "scan": st.scan_ms, "nodes": st.nodes_ms},
             "roofline": roof,
         }
+        out["step_roofline"] = step_roofline(out["ms_per_step"], n, u64)
         out["library"] = {"build_info": eng.build_info(), "product": _lib_is_product(), "source_digest": _digest()}
         if not sharded:
             out["per_step"] = step_spread(eng)
+            single_gpu_record(a, n, write={"ms_per_step": out["ms_per_step"], "steps": a.steps, "build_ms": st.build_ms,
+                                           "walk_ms": st.walk_ms, "source_digest": _digest()})
         out["rccl"] = ({"world_size": dist.get_world_size(), "backend": dist.get_backend()} if dist.is_initialized()
                        else {"world_size": 1, "backend": None})
         if phases:
@@ -512,6 +635,8 @@ def main():
             other = "uniform" if a.init == "plummer" else "plummer"
             m2, p2, v2 = IC.make(other, n, a.seed, quasi_static=True)
             leg, _, _ = timed_leg(G, cfg, m2, p2, v2, a.steps, a.warmup)
+            leg["roofline"] = walk_roofline(G, cfg, m2, p2, v2, leg["walk_ms"], FLAG_WALK_STATS)
+            leg["step_roofline"] = step_roofline(leg["ms_per_step"], n, leg["roofline"]["u64_nodes_per_body"])
             out["secondary"] = {"workload": f"{other}_N{n}_theta{a.theta}", **leg}
             # The headline workload is quasi-static (bodies do not change cells, so the sort permutation of
             # every timed step is the identity).  DYNAMIC leg: same N, theta, dtype and distribution, every
@@ -519,6 +644,8 @@ def main():
             # tiny: no close-encounter blow-up); reported with the measured churn of the sorted order.
             m3, p3, v3 = IC.make(a.init, n, a.seed, quasi_static=True, drift_cells=a.drift_cells)
             leg, q0, q1 = timed_leg(G, cfg, m3, p3, v3, a.steps, a.warmup)
+            leg["roofline"] = walk_roofline(G, cfg, m3, q0, v3, leg["walk_ms"], FLAG_WALK_STATS)
+            leg["step_roofline"] = step_roofline(leg["ms_per_step"], n, leg["roofline"]["u64_nodes_per_body"])
             out["dynamic"] = {"workload": f"{a.init}_N{n}_theta{a.theta}_drift{a.drift_cells}cells_per_step",
                               **leg, **rank_churn(q0, q1)}
             # The bit-exact fp64 mode (the parity anchor: the reference's own arithmetic, project.cu:38-65):
@@ -530,13 +657,23 @@ def main():
                                    reference_compat=True, device=local)
                 ks = max(3, a.steps // 4) if nn == n else 200
                 leg, _, _ = timed_leg(G, cfg_e, me, pe, ve, ks, 2)
+                leg["roofline"] = walk_roofline(G, cfg_e, me, pe, ve, leg["walk_ms"], FLAG_WALK_STATS, kind="exact")
+                leg["roofline"]["kernel"] = "walk_exact_kernel"
+                leg["step_roofline"] = step_roofline(leg["ms_per_step"], nn, leg["roofline"]["u64_nodes_per_body"],
+                                                     leg["build_bytes_per_body"], kind="f64")
                 ex[tag] = {"workload": f"{kind}_N{nn}_theta{a.theta}_depth{md}_exact_fp64", "steps": ks, **leg}
             out["secondary_exact"] = ex
-            # BH_PRECISION_F64: the same fp64 tree, the throughput walk (free order, four siblings per scalar load,
-            # v_rsq_f64 + Newton): the reference's arithmetic TYPE at speed; <= 1e-12 of the oracle, same counts
+            # BH_PRECISION_F64: the same fp64 tree, the throughput walk (hand-written loop, free order, four siblings per
+            # scalar load, criterion on d2, v_rsq_f64 + one Newton step): the reference's arithmetic TYPE at speed;
+            # <= 1e-12 of the oracle, same per-body counts
             cfg_f = G.BhConfig(capacity=n, theta=a.theta, max_depth=a.max_depth, precision=G.Precision.F64,
                                reference_compat=True, device=local)
             leg, _, _ = timed_leg(G, cfg_f, mass, pos, vel, max(5, a.steps // 2), 2, want_state=False)
+            leg["roofline"] = walk_roofline(G, cfg_f, mass, pos, vel, leg["walk_ms"], FLAG_WALK_STATS, kind="f64")
+            leg["roofline"]["kernel"] = "walk_f64_kernel"
+            leg["roofline"].update(committed_traffic("F64"))
+            leg["step_roofline"] = step_roofline(leg["ms_per_step"], n, leg["roofline"]["u64_nodes_per_body"],
+                                                 leg["build_bytes_per_body"], kind="f64")
             out["secondary_f64"] = {"workload": f"{a.init}_N{n}_theta{a.theta}_depth{a.max_depth}_fast_fp64", **leg}
         if world == 1 and not a.no_secondary and a.other_configs:
             out["other_configs"] = other_configs(G, IC, local, a.seed, FLAG_WALK_STATS,

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PRODUCT_LIB = os.path.join(HERE, "libbhgpu.so")
 LIB_PATH = os.environ.get("BHGPU_LIB") or PRODUCT_LIB
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class bh_config(C.Structure):
@@ -51,6 +51,7 @@ class bh_stats_t(C.Structure):
         ("sort_spill_buckets", C.c_uint64),
         ("let_tree_ms", C.c_double), ("let_pack_ms", C.c_double),
         ("sort_rerun_buckets", C.c_uint64),
+        ("wave_accepts", C.c_uint64), ("walk_launches", C.c_uint64),
     ]
 
 

@@ -11,8 +11,10 @@ namespace bh {
 // `slots` (may be null): kBoundSlots running {xlo, xhi, ylo, yhi} records that the workgroups of a launch fold their
 // bounds into with four atomics each (slot = workgroup index mod kBoundSlots).  The next build's keys_kernel reduces
 // those 64 records in every one of its workgroups -- 2 KB from L2 -- instead of waiting for a one-workgroup launch
-// that reduces thousands of partials (bounds_final: a 4 us dependent launch feeding 64 bytes), and its last workgroup
-// leaves the slots at +-inf again.  min / max are exact and order-free: the box is the same, bit for bit.
+// that reduces thousands of partials (bounds_final: a 4 us dependent launch feeding 64 bytes); prep_kernel, two launches
+// on, puts the slots back to +-inf (no reader counter: it was 4,100 atomics on one word).  Records that are still all
+// +-inf when keys_kernel reads them mean that the walk returned at once on an overflowed tree: the box in memory stays.
+// min / max are exact and order-free: the box is the same, bit for bit.
 constexpr int kBoundSlots = 64;
 __device__ __forceinline__ void bounds_to_slot(double xlo, double xhi, double ylo, double yhi, double *slots, uint32_t group)
 {

@@ -139,6 +139,7 @@ struct bh_ctx {
     int64_t steps_done = 0;
     int32_t last_nsteps = 0;
     int timed_pairs = 0;
+    int64_t walk_launches = 0;     // walk kernel launches of the last enqueue_walk
     bool step_timed = false;
 
     std::vector<void *> allocs;
@@ -261,12 +262,13 @@ int enqueue_build_t(bh_ctx *c)
     if (from_slots) {
         c->partial_count = 0; c->slots_valid = false; c->slots_dirty = false;   // (keys_kernel below consumes and resets them)
     } else if (!c->external_box) {
-        if (c->partial_count <= 0) {
+        const bool from_walk = c->partial_count > 0;
+        if (!from_walk) {
             const unsigned nbb = std::max(1u, std::min(1024u, blocks_for(n, kBlock)));
             hipLaunchKernelGGL((bounds_partial<Real2>), dim3(nbb), dim3(kBlock), 0, st, pos, n, c->partial);
             c->partial_count = (int)nbb;
         }
-        hipLaunchKernelGGL(bounds_final, dim3(1), dim3(kBlock), 0, st, c->partial, c->partial_count, c->box, c->ctr, Dm);
+        hipLaunchKernelGGL(bounds_final, dim3(1), dim3(kBlock), 0, st, c->partial, c->partial_count, c->box, c->ctr, Dm, from_walk ? 1 : 0);
         c->partial_count = 0; c->slots_valid = false;
     }   // else: let_box_kernel has set the global box and cleared the counters
 
@@ -449,7 +451,7 @@ int enqueue_build_t(bh_ctx *c)
         const int64_t span = std::max<int64_t>(1, std::min<int64_t>(c->internal_cap, std::max<int64_t>(n - 1, 0) * (int64_t)std::max(1, Dm)));
         hipLaunchKernelGGL(nodes_exact_kernel, dim3(blocks_for(span, kBlock)), dim3(kBlock), 0, st, c->keys_sorted, c->perm,
                            c->cnt, c->cell_first, pos, mass, c->box, n, Dm, c->internal_cap, c->gd, c->ld, c->self_node,
-                           c->cell_depth, c->com_pending, c->ctr);
+                           c->cell_depth, c->com_pending, c->ctr, c->fast64 ? c->cfg.theta : 0.0);
     } else {
         launch_nodes_fast(c, false, st);
     }
@@ -499,6 +501,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
     owned_range(c, &lo, &hi);
     if (hi <= lo) return BH_OK;
     const bool stats = (c->cfg.flags & BH_FLAG_WALK_STATS) != 0;
+    if (part != 2) c->walk_launches = 0;
     if (integrate) c->slots_valid = false;                         // (the positions change; the fp32 branch may set it again)
     // a full-range integrating walk also leaves the min/max of the NEW positions per workgroup
     const bool want_partial = integrate && !to_sorted && lo == 0 && hi == c->n;
@@ -521,23 +524,38 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
     }
     if (integrate) c->slots_valid = want_slots;
     if (c->exact && c->fast64) {
-        if (stats && !c->body_counts) { int rc = dev_alloc(c, &c->body_counts, (size_t)std::max<int64_t>(c->cfg.capacity, 1)); if (rc) return rc; }
+        if (stats) {
+            if (!c->body_counts) { int rc = dev_alloc(c, &c->body_counts, (size_t)std::max<int64_t>(c->cfg.capacity, 1)); if (rc) return rc; }
+            // (a launch writes the slots of the bodies it walks: an owned range smaller than n, or a walk that returned
+            // early on an overflowed tree, must not leave the others uninitialised)
+            BH_HIP(c, hipMemsetAsync(c->body_counts, 0, (size_t)std::max<int64_t>(c->n, 1) * sizeof(uint32_t), c->stream));
+        }
+        // hand-written loop (walk64_asm): 32-bit byte offsets into the node array; the counting variant and
+        // BH_FLAG_WALK_PORTABLE run the C++ statement of the same loop (same operations, same order, same bits)
+        const bool use_asm = c->walk_asm && !stats && !(c->cfg.flags & BH_FLAG_WALK_PORTABLE) &&
+                             c->node_cap * (int64_t)sizeof(NodeD) < (1ll << 32);
+        const bool deep = 3 * c->Dm + 1 > kWave;                 // (deeper than 21 levels: the two-tier stack)
         for (int64_t plo = lo; plo < hi; plo += pass) {
             const int64_t phi = std::min(hi, plo + pass);
             double *pp = partial ? partial + 4 * ((plo - lo) / kF64Block) : nullptr;
+            WalkF64Args wa{};
+            wa.gd = c->gd; wa.ld = c->ld; wa.perm = c->perm; wa.pos = (double2 *)c->pos; wa.vel = (double2 *)c->vel;
+            wa.mass = (const double *)c->mass; wa.force_out = (double2 *)c->force; wa.lo = plo; wa.hi = phi;
+            wa.G = c->cfg.G; wa.dt = c->cfg.dt; wa.integrate = integrate ? 1 : 0; wa.ctr = c->ctr; wa.partial = pp;
+            wa.body_counts = stats ? c->body_counts : nullptr; wa.slots = slots;
             auto args = [&](auto kern) {
-                hipLaunchKernelGGL(kern, dim3(blocks_for(phi - plo, kF64Block)), dim3(kF64Block), 0, c->stream, c->gd, c->ld, c->perm,
-                                   (double2 *)c->pos, (double2 *)c->vel, (const double *)c->mass,
-                                   (double2 *)c->force, plo, phi, c->cfg.theta, c->cfg.G, c->cfg.dt,
-                                   integrate ? 1 : 0, c->ctr, pp, stats ? c->body_counts : nullptr, slots);
+                hipLaunchKernelGGL(kern, dim3(blocks_for(phi - plo, kF64Block)), dim3(kF64Block), 0, c->stream, wa);
+                c->walk_launches += 1;
             };
-            if (3 * c->Dm + 1 > kWave) {                         // (deeper than 21 levels: the two-tier stack)
-                if (c->compat) { if (stats) args(walk_f64_kernel<true, true, true>); else args(walk_f64_kernel<true, false, true>); }
-                else           { if (stats) args(walk_f64_kernel<false, true, true>); else args(walk_f64_kernel<false, false, true>); }
-            } else {
-                if (c->compat) { if (stats) args(walk_f64_kernel<true, true>); else args(walk_f64_kernel<true, false>); }
-                else           { if (stats) args(walk_f64_kernel<false, true>); else args(walk_f64_kernel<false, false>); }
-            }
+            auto pick = [&](auto compat_tag, auto deep_tag) {
+                constexpr bool CP = decltype(compat_tag)::value, DP = decltype(deep_tag)::value;
+                if (stats) args(walk_f64_kernel<CP, true, DP, false>);
+                else if (use_asm) args(walk_f64_kernel<CP, false, DP, true>);
+                else args(walk_f64_kernel<CP, false, DP, false>);
+            };
+            using T = std::true_type; using Fz = std::false_type;
+            if (c->compat) { if (deep) pick(T{}, T{}); else pick(T{}, Fz{}); }
+            else           { if (deep) pick(Fz{}, T{}); else pick(Fz{}, Fz{}); }
         }
         per_partial = kF64Block;
         BH_HIP(c, hipGetLastError());
@@ -550,6 +568,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
                                    (double2 *)c->pos, (double2 *)c->vel, (const double *)c->mass,
                                    (double2 *)c->force, plo, phi, c->cfg.theta, c->cfg.G, c->cfg.dt,
                                    integrate ? 1 : 0, c->ctr, pp, slots);
+                c->walk_launches += 1;
             };
             if (c->compat) { if (stats) args(walk_exact_kernel<true, true>); else args(walk_exact_kernel<true, false>); }
             else           { if (stats) args(walk_exact_kernel<false, true>); else args(walk_exact_kernel<false, false>); }
@@ -611,6 +630,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
             a.lo = plo; a.hi = std::min(hi, plo + pass);
             a.partial = partial ? partial + 4 * ((plo - lo) / per_partial) : nullptr;
             BH_HIP(c, launch_walk_fast(a, lds, stats, split, use_asm, c->stream));
+            c->walk_launches += 1;
         }
     }
     if (want_partial) c->partial_count = (int)blocks_for(hi - lo, per_partial);
@@ -1198,6 +1218,7 @@ int bh_stats(bh_ctx *c, bh_stats_t *out)
     std::memset(out, 0, sizeof(*out));
     out->n_bodies = c->n;
     out->steps_done = c->steps_done;
+    out->walk_launches = (uint64_t)c->walk_launches;
     out->device_bytes = c->device_bytes;
     {
         TreeCounters h{};
@@ -1214,6 +1235,7 @@ int bh_stats(bh_ctx *c, bh_stats_t *out)
         out->interactions = h.interactions;
         out->wave_nodes = h.wave_nodes;
         out->wave_quads = h.wave_quads;
+        out->wave_accepts = h.wave_accepts;
     }
     if (c->let_timed) {
         float ms = 0.f;

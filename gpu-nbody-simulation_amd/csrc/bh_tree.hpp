@@ -73,15 +73,18 @@ __global__ __launch_bounds__(kBlock) void bounds_partial(const Real2 *__restrict
     }
 }
 
-__global__ void bounds_slots_reset(double *slots)                // one wave: records back to +-inf, reader counter to 0
+__global__ void bounds_slots_reset(double *slots)                // one wave: records back to +-inf
 {
     double *w = slots + 4 * threadIdx.x;
     w[0] = INFINITY; w[1] = -INFINITY; w[2] = INFINITY; w[3] = -INFINITY;
 }
 
-// final reduction + the padding of project.cu:553-570; also clears the per-step counters
+// final reduction + the padding of project.cu:553-570; also clears the per-step counters.
+// from_walk: the partials are what the previous walk's epilogue left.  A walk whose tree had outgrown node_capacity
+// returned at once and wrote none: the box and the overflow flag stay as they are (the bodies have not moved), so every
+// later step of the same bh_step call is a no-op too and bh_sync / bh_download report BH_ERR_CAPACITY.
 __global__ __launch_bounds__(kBlock) void bounds_final(const double *__restrict__ partial, int nb,
-                                                        double *__restrict__ box, TreeCounters *ctr, int Dm)
+                                                        double *__restrict__ box, TreeCounters *ctr, int Dm, int from_walk)
 {
     __shared__ double sm[4][kWavesPerBlock];
     double xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
@@ -99,14 +102,17 @@ __global__ __launch_bounds__(kBlock) void bounds_final(const double *__restrict_
             xlo = (sm[0][w] < xlo) ? sm[0][w] : xlo;  xhi = (xhi < sm[1][w]) ? sm[1][w] : xhi;
             ylo = (sm[2][w] < ylo) ? sm[2][w] : ylo;  yhi = (yhi < sm[3][w]) ? sm[3][w] : yhi;
         }
-        const double ex = xhi - xlo, ey = yhi - ylo;
-        const double span = (ex < ey) ? ey : ex;
-        double pad = 0.1 * span;
-        if (span == 0.0) pad = 1e-6;
-        box[0] = xlo - pad; box[1] = xhi + pad; box[2] = ylo - pad; box[3] = yhi + pad;
-        write_key_consts(box, Dm);
-        ctr->n_internal = 0; ctr->overflow = 0;
-        ctr->visits = 0; ctr->interactions = 0; ctr->wave_nodes = 0; ctr->wave_quads = 0;
+        if (!(from_walk && ctr->overflow)) {
+            const double ex = xhi - xlo, ey = yhi - ylo;
+            const double span = (ex < ey) ? ey : ex;
+            double pad = 0.1 * span;
+            if (span == 0.0) pad = 1e-6;
+            box[0] = xlo - pad; box[1] = xhi + pad; box[2] = ylo - pad; box[3] = yhi + pad;
+            write_key_consts(box, Dm);
+            ctr->overflow = 0;
+        }
+        ctr->n_internal = 0;
+        ctr->visits = 0; ctr->interactions = 0; ctr->wave_nodes = 0; ctr->wave_quads = 0; ctr->wave_accepts = 0;
     }
 }
 
@@ -269,26 +275,42 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
     // follow; prep_kernel, two launches on, puts the slots back to +-inf for the next walk.  (A counter of readers
     // that let the last workgroup do that here made this kernel 51 us instead of 10: 4,100 atomics on one word.)
     __shared__ double s_box[FROM_SLOTS ? 8 : 1];
+    __shared__ int s_empty;
     if (FROM_SLOTS) {
         if (threadIdx.x < kWave) {
             const double *sl = slots + 4 * threadIdx.x;
             const double xlo = wave_min(sl[0]), xhi = wave_max(sl[1]), ylo = wave_min(sl[2]), yhi = wave_max(sl[3]);
+            // No workgroup folded anything (every record still +-inf): the previous walk returned at once because its tree
+            // had outgrown node_capacity (`if (ctr->overflow) return`), so the bodies have not moved.  Keep the box in
+            // memory and leave the overflow flag standing -- this build's walk then does nothing either, and the state
+            // stays the last good one until bh_sync / bh_download report BH_ERR_CAPACITY (a box of {+inf, -inf}
+            // gave every body the same key, a short tree that did NOT overflow, and a step integrated with garbage forces).
+            const bool empty = xlo > xhi;
+            if (threadIdx.x == 0) s_empty = empty ? 1 : 0;
             if (threadIdx.x < 2) {                               // lane a: axis a (four fp64 divisions in a row otherwise)
-                const double ex = xhi - xlo, ey = yhi - ylo;
-                const double span = (ex < ey) ? ey : ex;
-                double pad = 0.1 * span;
-                if (span == 0.0) pad = 1e-6;
                 const int a = threadIdx.x;
-                s_box[2 * a] = (a ? ylo : xlo) - pad; s_box[2 * a + 1] = (a ? yhi : xhi) + pad;
-                write_key_consts_axis(s_box, a, Dm);
+                if (empty) {
+                    s_box[2 * a] = box_global[2 * a]; s_box[2 * a + 1] = box_global[2 * a + 1];
+                    s_box[4 + a] = box_global[4 + a]; s_box[6 + a] = box_global[6 + a];
+                } else {
+                    const double ex = xhi - xlo, ey = yhi - ylo;
+                    const double span = (ex < ey) ? ey : ex;
+                    double pad = 0.1 * span;
+                    if (span == 0.0) pad = 1e-6;
+                    s_box[2 * a] = (a ? ylo : xlo) - pad; s_box[2 * a + 1] = (a ? yhi : xhi) + pad;
+                    write_key_consts_axis(s_box, a, Dm);
+                }
             }
         }
         __syncthreads();
         if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (!s_empty) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) box_global[k] = s_box[k];
-            ctr->n_internal = 0; ctr->overflow = 0;
-            ctr->visits = 0; ctr->interactions = 0; ctr->wave_nodes = 0; ctr->wave_quads = 0;
+                for (int k = 0; k < 8; ++k) box_global[k] = s_box[k];
+                ctr->overflow = 0;
+            }
+            ctr->n_internal = 0;
+            ctr->visits = 0; ctr->interactions = 0; ctr->wave_nodes = 0; ctr->wave_quads = 0; ctr->wave_accepts = 0;
         }
     }
     // (a template parameter, not a run-time test: read through a pointer that is either in LDS or in memory the eight values
@@ -580,6 +602,17 @@ __device__ __forceinline__ int64_t cell_end(const uint64_t *__restrict__ keys, i
     return lower_bound_prefix(keys, a + 1, b, sh, pfx + 1);
 }
 
+// BH_PRECISION_F64 (bh_walk_f64.hpp) -- what the node kernel stores in NodeD::size for that walk: the acceptance criterion size / (sqrt(d2) + 1e-15) < theta
+// (project.cu:634, 643) solved for d2.  A cell so small that size / theta < 1e-15 is accepted at every distance (-1 < d2);
+// a non-finite size accepts nobody, as every comparison with a NaN fails (+inf < d2 never holds).
+__device__ __forceinline__ double f64_walk_threshold(double size, double theta)
+{
+    const double s = size / theta - 1e-15;
+    if (s >= 0.0) return s * s;
+    if (s < 0.0) return -1.0;
+    return (double)INFINITY;
+}
+
 // ---- exact-mode nodes kernel: one thread per subdivided cell writes its four children ---------------
 // NodeD/LinkD + self_node / pending (subdivided children per cell) for the bottom-up pass.  Round 1 ran one
 // thread per sorted neighbour pair, and the pair that starts a chain of nested cells handled them in turn:
@@ -595,8 +628,10 @@ __global__ __launch_bounds__(kBlock) void nodes_exact_kernel(
     const double2 *__restrict__ pos, const double *__restrict__ mass,
     const double *__restrict__ box, int64_t n, int Dm, int64_t internal_cap, NodeD *__restrict__ gd,
     LinkD *__restrict__ ld, int32_t *__restrict__ self_node, int32_t *__restrict__ cell_depth,
-    uint32_t *__restrict__ pending, TreeCounters *ctr)
+    uint32_t *__restrict__ pending, TreeCounters *ctr, double walk_theta)
 {
+    // walk_theta > 0 (BH_PRECISION_F64): the `size` slot of every node carries the walk's d2 threshold instead
+    auto size_slot = [&](double size) { return walk_theta > 0.0 ? f64_walk_threshold(size, walk_theta) : size; };
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint32_t total = ctr->n_internal;
 
@@ -620,7 +655,7 @@ __global__ __launch_bounds__(kBlock) void nodes_exact_kernel(
             occ = (int)b;
         }
         const double ex = box[1] - box[0], ey = box[3] - box[2];
-        gd[0] = NodeD{cx, cy, m, (ex > ey) ? ex : ey};
+        gd[0] = NodeD{cx, cy, m, size_slot((ex > ey) ? ex : ey)};
         ld[0] = LinkD{-1, occ};
         return;
     }
@@ -712,7 +747,7 @@ __global__ __launch_bounds__(kBlock) void nodes_exact_kernel(
 
     if (d == 0) {                                  // root record (mass/COM come bottom-up)
         const double ex = x1 - x0, ey = y1 - y0;
-        gd[0].size = (ex > ey) ? ex : ey;
+        gd[0].size = size_slot((ex > ey) ? ex : ey);
         ld[0] = LinkD{quad, -1};
         self_node[0] = 0;
     }
@@ -776,7 +811,7 @@ __global__ __launch_bounds__(kBlock) void nodes_exact_kernel(
             ++n_sub;
         }
         double *sn = s_nd + threadIdx.x * 16 + 4 * c;
-        sn[0] = cx; sn[1] = cy; sn[2] = m; sn[3] = size;
+        sn[0] = cx; sn[1] = cy; sn[2] = m; sn[3] = size_slot(size);
         s_ln[threadIdx.x * 8 + 2 * c] = child; s_ln[threadIdx.x * 8 + 2 * c + 1] = occ;
     }
     pending[r] = n_sub;
@@ -1250,7 +1285,10 @@ __global__ __launch_bounds__(kBlock) void com_up_kernel(NodeD *__restrict__ gd, 
 // The same pass, one launch per depth (deepest first): what large trees use.  com_up_kernel's agent-scope
 // acquire-release RMW costs a write-back / invalidate of the non-coherent per-XCD L2s per cell: measured
 // 15 us at N = 1,024, 50 us at 65,536 (= nine launches of this kernel), 1.75 ms at N = 1M against ~0.15 ms for
-// twenty launches of this one.  Same sums in the same order either way.
+// twenty launches of this one.  Same sums in the same order either way.  (Round 4 built the pass in 2-3 launches -- a block of
+// consecutive pre-order ranks holds whole subtrees, the cells it cannot finish are one chain of ancestors, lists of those chains
+// are finished over 64 x larger ranges per launch -- once as a separate kernel and once started inside nodes_exact_kernel:
+// 107 and 136 us against these 112, each bitwise equal; profiles/r04_f64/com_ab.txt says where the time went.)
 __global__ __launch_bounds__(kBlock) void com_level_kernel(NodeD *__restrict__ gd, const int32_t *__restrict__ self_node,
                                                             const int32_t *__restrict__ cell_depth,
                                                             const TreeCounters *__restrict__ ctr, int64_t internal_cap,
@@ -1273,5 +1311,6 @@ __global__ __launch_bounds__(kBlock) void com_level_kernel(NodeD *__restrict__ g
     if (tot > 0.0) { sx /= tot; sy /= tot; }
     gd[node].cx = sx; gd[node].cy = sy; gd[node].m = tot;
 }
+
 
 }  // namespace bh

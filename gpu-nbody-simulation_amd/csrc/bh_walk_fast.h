@@ -32,7 +32,7 @@ struct WalkFastArgs {
     const void *bucket_consts;     // device block {aux, spos, smass, 0}: the assembly loop's bucket path reads its pointers here
     uint32_t *group_cost;          // per 64-body group: loop iterations of its walk (load-balancing weight), may be null
     int32_t pair_limit;            // one-wave walk: two stack entries per iteration while sp <= pair_limit
-                                   // (120 - 3 * (max_depth - 1), never negative: the 128-entry stack bound)
+                                   // (116 - 3 * (max_depth - 1), never negative: the 128-entry stack bound, bh_walk_fast.hip)
     uint64_t *timeline;            // -DBHGPU_EXPERIMENTS builds: per-wave {start, end, hw id, cost} (scripts/walk_timeline.py)
     // forest walk (distributed step): besides the local tree (root quad 0) the bodies walk the
     // locally-essential trees received from the peers, whose root quads sit at

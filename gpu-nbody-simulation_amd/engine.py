@@ -76,6 +76,8 @@ class BhStats:
     let_tree_ms: float = 0.0    # last let_build: global box + local tree
     let_pack_ms: float = 0.0    # last let_build: LET marking / numbering / packing
     sort_rerun_buckets: int = 0  # bucket-sort buckets whose short sort met a long run and was repeated in full (bh_sort.hpp)
+    wave_accepts: int = 0       # FLAG_WALK_STATS, Precision.F64: nodes some lane accepted, once per wavefront
+    walk_launches: int = 0      # walk kernel launches of the last step (1, or the passes of n_threads)
 
 
 def _dptr(a: np.ndarray):
@@ -174,7 +176,7 @@ class BarnesHutEngine:
         return a
 
     def interaction_counts(self) -> np.ndarray:
-        """Accepted force evaluations per body of the last walk (FLAG_WALK_STATS; fp32 / mixed), caller order."""
+        """Accepted force evaluations per body of the last walk (FLAG_WALK_STATS; fp32 / mixed / Precision.F64), caller order."""
         c = np.zeros(max(self.n, 1), dtype=np.uint32)
         self._check(self._lib.bh_get_interaction_counts(self._h, c.ctypes.data_as(C.POINTER(C.c_uint32))))
         return c[:self.n]
@@ -203,7 +205,7 @@ class BarnesHutEngine:
         return BhStats(s.n_bodies, s.n_nodes, s.n_internal, s.steps_done, s.visits, s.interactions,
                        s.wave_nodes, s.last_step_ms, s.build_ms, s.walk_ms, s.device_bytes, s.keys_ms, s.sort_ms,
                        s.scan_ms, s.nodes_ms, s.build_bytes, s.walk_bytes, s.wave_quads, s.sort_spill_buckets,
-                       s.let_tree_ms, s.let_pack_ms, s.sort_rerun_buckets)
+                       s.let_tree_ms, s.let_pack_ms, s.sort_rerun_buckets, s.wave_accepts, s.walk_launches)
 
     def step_times(self):
         """(step_ms[k], walk_ms[k]) of the steps of the last step() call (at most 4,096): HIP events per step."""

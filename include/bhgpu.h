@@ -27,9 +27,10 @@
 extern "C" {
 #endif
 
-#define BHGPU_ABI_VERSION 3   /* 2: bh_stats_t carries per-kernel-group times and algorithmic bytes;
+#define BHGPU_ABI_VERSION 4   /* 2: bh_stats_t carries per-kernel-group times and algorithmic bytes;
                                  3: bh_get_interaction_counts, bh_build_info, bh_step_times,
-                                    bh_stats_t.let_*_ms */
+                                    bh_stats_t.let_*_ms;
+                                 4: bh_stats_t.wave_accepts, .walk_launches (the struct grew) */
 
 typedef enum bh_status {
     BH_OK = 0,
@@ -54,8 +55,9 @@ typedef enum bh_precision {
      * of the coordinates.  Single-GPU step and the LET distributed step; not the replicated one. */
     BH_PRECISION_MIXED = 2,
     /* fp64 end to end like the reference (project.cu:38-65) at THROUGHPUT: the tree is the exact mode's, node
-     * for node bitwise the reference's; the walk takes the fp32 kernel's design (four sibling nodes per scalar
-     * load, free visiting order, 1/d by v_rsq_f64 + Newton steps instead of sqrt and three divisions).  Forces agree
+     * for node bitwise the reference's; the walk takes the fp32 kernel's design (a hand-written gfx950 loop, four sibling
+     * nodes per scalar load, free visiting order, the acceptance criterion of project.cu:643 as one compare on d^2, 1/d by
+     * v_rsq_f64 + ONE Newton step instead of sqrt and three divisions).  Forces agree
      * with the reference CPU path to summation rounding (<= 1e-12 relative, same per-body interaction counts), not
      * bit for bit; trajectories therefore diverge from it as fast as the dynamics amplify 1e-15.  reference_compat,
      * max_depth and the empty-node cut-off mean what they mean in BH_PRECISION_F64_EXACT.  Single GPU. */
@@ -75,7 +77,7 @@ typedef enum bh_precision {
                                            bodies its launch walks (still reproducible run to
                                            run).  Set this to rule that out.                 */
 
-#define BH_FLAG_WALK_PORTABLE (1u << 3) /* fp32 walk: the C++ traversal loop instead of the
+#define BH_FLAG_WALK_PORTABLE (1u << 3) /* fp32 and BH_PRECISION_F64 walks: the C++ traversal loop instead of the
                                            hand-scheduled gfx950 assembly loop.  Same operations
                                            in the same order -- results are bit-identical; kept
                                            as the readable statement of the loop and for tests. */
@@ -149,6 +151,12 @@ typedef struct bh_stats_t {
     uint64_t sort_rerun_buckets; /* buckets of the bucket sort whose short sort (the top 24 bits of the keys' span, then
                                     runs of equal top bits by counting) met a run of more than 8 keys and was repeated
                                     with all byte passes, since bh_create (0 unless bodies pile up)          */
+    /* ABI 4 */
+    uint64_t wave_accepts;       /* BH_FLAG_WALK_STATS, BH_PRECISION_F64: nodes some lane of the wavefront accepted, counted once
+                                    per wavefront -- the nodes that pay the reciprocal square root and the force (the
+                                    others stop at the compare); 0 in the other precisions                          */
+    uint64_t walk_launches;      /* walk kernel launches of the last bh_step / bh_compute_forces step: 1, or the passes
+                                    of n_threads (project.cu:703)                                              */
 } bh_stats_t;
 
 typedef struct bh_ctx bh_ctx;

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Condense a gpurun_out/<tag>/ profile directory (scripts/gpu_profile.sh) into profiles/<name>/:
 kernel_stats.csv (rocprofv3 --kernel-trace --stats), pmc_summary.csv (per-kernel counter means) and
-bench.json.  usage: summarize_profile.py gpurun_out/<tag> profiles/<name>"""
+bench.json.  usage: summarize_profile.py gpurun_out/<tag> profiles/<name> [--tag C2|C4|C5|F64] [--no-latest]
+--tag: the profile is of another configuration than the headline: its traffic goes to profiles/latest_walk_traffic_<tag>.json,
+which bench.py reads for that leg (other_configs.<tag>.roofline.traffic / secondary_f64.roofline.traffic)."""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -9,6 +11,7 @@ from gpu_nbody_simulation_amd.build import source_digest  # noqa: E402
 
 src, dst = sys.argv[1], sys.argv[2]
 update_latest = "--no-latest" not in sys.argv[3:]          # other configurations than the headline: keep profiles/latest_*
+tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else None
 os.makedirs(dst, exist_ok=True)
 latest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
 shutil.copy(latest(f"{src}/trace/runc/*_kernel_stats.csv"), f"{dst}/kernel_stats.csv")
@@ -33,15 +36,21 @@ with open(f"{dst}/pmc_summary.csv", "w", newline="") as fh:
 # of the bytes read -- calibrated for THIS kernel's access pattern (wave-uniform 64-byte scalar
 # loads) with scripts/calib/fetch_calib.hip: ratio 0.50003 -- so reads = 2 * FETCH_SIZE.
 # the product walk of the run: the hand-scheduled kernel, or the C++ loop where the engine had to fall back to it
-walk = {c: v for (k, c, n, v) in rows if k.startswith("void bh::walk_fast_kernel<false, false, 1, true>")} or \
-       {c: v for (k, c, n, v) in rows if k.startswith("void bh::walk_fast_kernel<false, false, 1, false>")}
+prefix = "void bh::walk_f64_kernel" if tag == "F64" else "void bh::walk_fast_kernel"
+names = collections.Counter()
+for (k, c, n, v) in rows:
+    if k.startswith(prefix) and c == "FETCH_SIZE":
+        names[k] += n
+# the product walk of the run = the instantiation with the most dispatches (one wave per group at C3-C5, four at C2)
+wname = names.most_common(1)[0][0] if names else None
+walk = {c: v for (k, c, n, v) in rows if k == wname}
 calib = {}
 for f in glob.glob(f"{src}/calib/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         if r["Kernel_Name"].startswith("k_") and r["Counter_Name"] == "FETCH_SIZE":
             calib[r["Kernel_Name"].split("(")[0]] = float(r["Counter_Value"]) * 1024 / 2**30
 if "FETCH_SIZE" in walk and "WRITE_SIZE" in walk:
-    t = {"kernel": "walk_fast_kernel", "fetch_size_kb": walk["FETCH_SIZE"], "write_size_kb": walk["WRITE_SIZE"],
+    t = {"kernel": wname.split("(")[0].replace("void bh::", ""), "fetch_size_kb": walk["FETCH_SIZE"], "write_size_kb": walk["WRITE_SIZE"],
          "fetch_correction": 2.0, "traffic_bytes": 2.0 * walk["FETCH_SIZE"] * 1024 + walk["WRITE_SIZE"] * 1024,
          "l2_hit_rate": walk.get("TCC_HIT_sum", 0) / max(1.0, walk.get("TCC_HIT_sum", 0) + walk.get("TCC_MISS_sum", 0)),
          "calibration_fetch_size_over_true_bytes": calib, "source": os.path.basename(dst),
@@ -49,7 +58,9 @@ if "FETCH_SIZE" in walk and "WRITE_SIZE" in walk:
          "source_digest": source_digest(),
          "git_head": subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None}
     json.dump(t, open(f"{dst}/walk_traffic.json", "w"), indent=1)
-    if update_latest:
+    if tag:
+        json.dump(t, open(os.path.join(os.path.dirname(dst.rstrip("/")), f"latest_walk_traffic_{tag}.json"), "w"), indent=1)
+    elif update_latest:
         json.dump(t, open(os.path.join(os.path.dirname(dst.rstrip("/")), "latest_walk_traffic.json"), "w"), indent=1)
     print(json.dumps(t))
 print(open(f"{dst}/kernel_stats.csv").read()[:1800])

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_abi_version():
-    assert _lib.load().bh_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.load().bh_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_struct_layouts_match_the_header(tmp_path):

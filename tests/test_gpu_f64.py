@@ -1,7 +1,7 @@
 """GPU parity, BH_PRECISION_F64 (the reference's arithmetic type at throughput, csrc/bh_walk_f64.hpp).
 
 The tree is the exact mode's -- checked bitwise against the reference's golden tree -- and the walk may visit nodes
-in another order and takes 1/d from v_rsq_f64 + Newton steps, so the stated tolerance is on the FORCES:
+in another order, decides acceptance on d^2 and takes 1/d from v_rsq_f64 + one Newton step, so the stated tolerance is on the FORCES:
     per body |F_gpu - F_ref| <= 1e-12 * |F_ref|      (reference = golden forces of project.cu's CPU path / the oracle)
     per body: the same number of accepted force evaluations as the oracle (the same acceptance decisions)
 and on short trajectories <= 1e-11 x box width (the integration is the reference's kick-drift in fp64; the
@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 from oracle import bh_oracle as O  # noqa: E402
 import gpu_nbody_simulation_amd as G  # noqa: E402
 from gpu_nbody_simulation_amd import initial_conditions as IC  # noqa: E402
-from gpu_nbody_simulation_amd.engine import FLAG_WALK_STATS  # noqa: E402
+from gpu_nbody_simulation_amd.engine import FLAG_WALK_PORTABLE, FLAG_WALK_STATS  # noqa: E402
 
 TOL = 1e-12
 
@@ -128,3 +128,34 @@ def test_full_size_slice_and_properties():
     ok = np.isfinite(d.forces[lo:hi]).all(axis=1)
     assert rel(f[lo:hi][ok], d.forces[lo:hi][ok]).max() <= TOL
     assert np.array_equal(cnt[lo:hi][ok], d.counts[lo:hi][ok])
+
+
+@pytest.mark.parametrize("kind,n,md,compat,theta", [("plummer", 20000, 21, False, 0.5), ("uniform", 65536, 21, True, 0.5),
+                                                    ("clumped", 30000, 8, False, 0.5), ("clumped", 30000, 8, True, 0.5),
+                                                    ("plummer", 30000, 32, False, 0.3), ("clumped", 20000, 32, True, 0.5),
+                                                    ("uniform", 130, 4, True, 0.5), ("uniform", 1, 21, True, 0.5)])
+def test_asm_walk_equals_the_portable_walk(kind, n, md, compat, theta):
+    """The hand-written gfx950 traversal loop (walk64_asm, csrc/bh_walk_f64.hpp) performs the same operations in the same
+    order as the C++ loop beside it (BH_FLAG_WALK_PORTABLE; BH_FLAG_WALK_STATS runs that loop with counters): forces after
+    one evaluation and the state after 3 steps are BITWISE equal -- subdivided cells, leaves and the occupant test,
+    depth-cap aggregates with the reference's occupant code (compat on), the empty-node cut-off, the two-tier stack of
+    trees deeper than 21 levels (max_depth 32), a ragged last wave, a one-body tree (the loop is never entered)."""
+    if kind == "clumped":
+        rng = np.random.default_rng(5)
+        p = np.concatenate([rng.normal(0, 1e-3, (n // 2, 2)), rng.uniform(-1, 1, (n - n // 2, 2))])
+        m, v = rng.uniform(0.1, 0.5, n), rng.uniform(-1e-9, 1e-9, (n, 2))
+        m[::7] = 1e-16                                                          # below the reference's 1e-15 cut-off
+    else:
+        m, p, v = IC.make(kind, n, 3, quasi_static=True)
+    res = []
+    for flags in (0, FLAG_WALK_PORTABLE, FLAG_WALK_STATS):
+        with engine(n, max_depth=md, reference_compat=compat, theta=theta, flags=flags) as e:
+            e.upload(p, v, m)
+            f = e.compute_forces()
+            e.step(3)
+            res.append((f,) + e.download())
+    if n > 1:
+        assert np.nanmax(np.abs(res[0][0])) > 0
+    for other in res[1:]:
+        for x, y in zip(res[0], other):
+            assert np.array_equal(x, y, equal_nan=True)

@@ -96,11 +96,12 @@ def test_reference_scaling_script_lines_run_unchanged(tmp_path):
 def test_n_threads_limits_the_bodies_walked_at_a_time_and_changes_no_result(precision, init1024):
     """N_THREADS (project.cu:5-7, 703): the walk takes the bodies in passes of n_threads (whole 256-thread workgroups),
     one launch after the other -- the axis of the reference's first scaling experiment (first_scaling_script.sh:17-36).
-    Same bodies, same tree, same per-body sums: results bitwise equal for every n_threads; the time is not."""
+    Same bodies, same tree, same per-body sums: results bitwise equal for every n_threads; the number of walk launches per
+    step is what changes (bh_stats_t.walk_launches)."""
     m, p, v = init1024
     if precision == G.Precision.F32:
         m, p, v = (x.astype(np.float32).astype(np.float64) for x in (m, p, v))
-    out, ms = [], []
+    out, launches = [], []
     for nt in (0, 1, 300, 1024):
         # (fp32: one wavefront per 64 bodies on both sides -- a pass is one thread per body; without the cap a launch
         # this small would let 8 wavefronts share each group, another order of the fp32 sums)
@@ -109,10 +110,11 @@ def test_n_threads_limits_the_bodies_walked_at_a_time_and_changes_no_result(prec
             e.upload(p, v, m)
             e.step(3)
             out.append(e.download())
-            ms.append(e.stats().walk_ms)
+            launches.append(e.stats().walk_launches)
     for pp, vv in out[1:]:
         assert np.array_equal(pp, out[0][0]) and np.array_equal(vv, out[0][1])
-    assert ms[1] > 1.5 * ms[0]                   # one workgroup at a time (4 passes) against all four at once
+    # the mechanism, not a timing: passes of ceil(n_threads / 256) workgroups, one launch each
+    assert launches == [1, 4, 2, 1]
 
 
 def test_overflow_is_reported_by_sync_after_step():
@@ -125,3 +127,43 @@ def test_overflow_is_reported_by_sync_after_step():
         with pytest.raises(G.BhError) as ei:
             e.sync()
         assert ei.value.code == -4
+
+
+@pytest.mark.parametrize("precision", [G.Precision.F32, G.Precision.F64, G.Precision.F64_EXACT])
+@pytest.mark.parametrize("nsteps", [2, 3])
+def test_overflow_inside_a_multi_step_call_keeps_the_last_good_state(precision, nsteps):
+    """a tree that outgrows node_capacity in step s of bh_step(k) makes that step's walk return at once -- and it
+    used to leave the bounds slots at +-inf, from which step s + 1 built a box of {+inf, -inf}, a short garbage tree that
+    did NOT overflow, and integrated every body with wrong forces; bh_sync then said BH_OK.  Now the empty reduction keeps
+    the box and the flag: every step of the call is a no-op, sync and download raise -4, and the device state is the
+    uploaded one, bit for bit."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+
+    def peek(ptr, count, dtype):                                               # (bh_download refuses, rightly: read the device arrays directly)
+        out = np.empty(count, dtype=dtype)
+        assert hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(out.nbytes), 2) == 0    # hipMemcpyDeviceToHost
+        return out.astype(np.float64)
+    r = np.random.default_rng(0)
+    n = 4096
+    m, p, v = 10.0 ** r.uniform(-2, 1, n), r.uniform(-0.1, 0.1, (n, 2)), r.uniform(-1e-4, 1e-4, (n, 2))
+    f32 = precision == G.Precision.F32
+    if f32:
+        m, p, v = (x.astype(np.float32).astype(np.float64) for x in (m, p, v))
+    with G.BarnesHutEngine(G.BhConfig(capacity=n, node_capacity=101, precision=precision, max_depth=16)) as e:
+        e.upload(p, v, m)
+        e.step(nsteps)
+        with pytest.raises(G.BhError) as ei:
+            e.sync()
+        assert ei.value.code == -4
+        with pytest.raises(G.BhError) as ei:
+            e.download()
+        assert ei.value.code == -4
+        dp, dv, _, dn, eb = e.device_state()
+        assert dn == n and eb == (4 if f32 else 8)
+        ts = np.float32 if f32 else np.float64
+        gp, gv = peek(dp, 2 * n, ts).reshape(n, 2), peek(dv, 2 * n, ts).reshape(n, 2)
+    # (fp32 mode keeps its state in the sorted order of its first build: compare as sets of (x, y, vx, vy) rows)
+    a = np.hstack([gp, gv]); b = np.hstack([p, v])
+    a = a[np.lexsort(a.T[::-1])]; b = b[np.lexsort(b.T[::-1])]
+    assert np.array_equal(a, b)

@@ -88,6 +88,55 @@ def test_the_one_wave_kernel_really_is_the_hand_written_loop(compiled):
     assert "s_load_dwordx16 s[48:63]" in body and "s_load_dwordx16 s[24:39]" in body and "v_cmpx_lt_f32_e32" in body
 
 
+@pytest.fixture(scope="module")
+def engine_asm(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(os.path.dirname(SRC), "bh_engine.hip")
+    out = tmp_path_factory.mktemp("engine") / "engine.s"
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-S", "--cuda-device-only",
+                        "-w", "-o", str(out), src], cwd=os.path.dirname(src), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out.read_text()
+
+
+F64_KERNEL = re.compile(r"_ZN2bh15walk_f64_kernelILb([01])ELb([01])ELb([01])ELb([01])EEEv")    # <COMPAT, STATS, DEEP, ASM>
+
+
+def test_every_fp64_assembly_walk_kernel_has_no_scratch_no_spills_and_fits_its_ceilings(engine_asm):
+    """walk64_asm (csrc/bh_walk_f64.hpp, round 4) pins s24..s72 and v20..v47 like the fp32 loop pins its block, with the same
+    consequence: s32 is only an ordinary register while the kernel has no private segment, and a spilled SGPR would sit in
+    a VGPR lane the block may clobber.  All four instantiations the launcher reaches (reference_compat on / off x one / two
+    stack tiers): no scratch, no spills, <= 80 SGPRs and <= 64 VGPRs -- 8 resident waves per SIMD: with one quad in flight per
+    wave this walk answers to residency (measured at N = 1M, profiles/r04_f64/walk_ab.txt: 0.704 ms at 7 waves, 0.800 at 5,
+    0.834 at 4, 1.088 at 3) --; and the loop in the code object is the hand-written one."""
+    ks = {}
+    for m in re.finditer(r"\.name:\s+(_ZN2bh15walk_f64_kernel\S+)\n", engine_asm):
+        meta = engine_asm[m.start():m.start() + 3000]
+        val = lambda key: int(re.search(key + r":\s+(\d+)", meta).group(1))
+        ks[m.group(1)] = {"sgpr": val(r"\.sgpr_count"), "vgpr": val(r"\.vgpr_count"), "sgpr_spill": val(r"\.sgpr_spill_count"),
+                          "vgpr_spill": val(r"\.vgpr_spill_count"), "scratch": val(r"\.private_segment_fixed_size"),
+                          "dynamic_stack": re.search(r"\.uses_dynamic_stack:\s+(\w+)", meta).group(1)}
+    asm = {k: v for k, v in ks.items() if F64_KERNEL.match(k).group(4) == "1"}
+    assert sorted((F64_KERNEL.match(k).group(1), F64_KERNEL.match(k).group(3)) for k in asm) == [("0", "0"), ("0", "1"), ("1", "0"), ("1", "1")]
+    for name, r in asm.items():
+        assert F64_KERNEL.match(name).group(2) == "0", name                      # (the counting variant is the C++ loop)
+        assert r["scratch"] == 0 and r["dynamic_stack"] == "false", (name, r)
+        assert r["sgpr_spill"] == 0 and r["vgpr_spill"] == 0, (name, r)
+        assert r["sgpr"] <= 80 and r["vgpr"] <= 64, (name, r)
+        body = engine_asm[engine_asm.index("\n" + name + ":"):]
+        body = body[:body.index("s_endpgm", body.index("Ldone_"))]
+        assert "s_load_dwordx16 s[24:39]" in body and "s_load_dwordx16 s[40:55]" in body and "s_load_dwordx8 s[56:63]" in body
+        assert body.count("v_cmpx_lt_f64_e32") == 4 and body.count("v_rsq_f64_e32") >= 4
+        deep = F64_KERNEL.match(name).group(3) == "1"
+        assert ("LpushHi0_" in body) == deep and ("LpopHi_" in body) == deep
+        compat = F64_KERNEL.match(name).group(1) == "1"
+        assert body.count("v_cmpx_ne_u32_e32") == (8 if compat else 4)
+    for name, r in ks.items():
+        assert r["scratch"] == 0 and r["vgpr_spill"] == 0, (name, r)
+
+
 def test_no_build_or_fp64_walk_kernel_uses_scratch(tmp_path):
     """Every kernel of the engine unit (tree build, sorts, LET, exact and fp64 walks) keeps its working set in registers
     and LDS: private_segment_fixed_size == 0 and no vector-register spills.  (Round 3: bucket_sort_kernel, whose 1,024-thread workgroups
