@@ -597,7 +597,20 @@ def main():
             if wq:
                 valu = ss.wave_nodes * VALU_CYCLES_PER_CHILD + wq * VALU_CYCLES_PER_QUAD
                 roof["issue_frac"] = valu / (N_SIMDS * walk_ms * 1e-3 * SHADER_CLOCK_HZ)
-                roof["issue"] = {"valu_cycles_per_launch": valu, "simd_cycles_per_launch": N_SIMDS * walk_ms * 1e-3 * SHADER_CLOCK_HZ,
+                # the in-kernel clock of this kernel, measured on the experiments build of the SAME sources (scripts/
+                # walk_timeline.py -> profiles/latest_walk_clock.json; MI355X_MICROARCH.md DVFS item 6): not reported for other kernels
+                clk = None
+                try:
+                    with open(os.path.join(ROOT, "profiles", "latest_walk_clock.json")) as fh:
+                        cj = json.load(fh)
+                    if cj.get("source_digest") == digest and n == 1 << 20 and a.init == "plummer":
+                        clk = cj["clock_hz_median"]
+                except (OSError, KeyError, ValueError):
+                    pass
+                if clk:
+                    roof["issue_frac_at_measured_clock"] = valu / (N_SIMDS * walk_ms * 1e-3 * clk)
+                roof["issue"] = {"clock_hz_measured": clk,
+                                 "valu_cycles_per_launch": valu, "simd_cycles_per_launch": N_SIMDS * walk_ms * 1e-3 * SHADER_CLOCK_HZ,
                                  "quads_per_launch": wq, "children_per_launch": ss.wave_nodes,
                                  "cycles_per_child": VALU_CYCLES_PER_CHILD, "cycles_per_quad": VALU_CYCLES_PER_QUAD,
                                  "clock_hz_assumed": SHADER_CLOCK_HZ}

@@ -24,6 +24,18 @@
 
 using namespace bh;
 
+// The one place the product translation unit knows about A/B builds: -DBHGPU_EXPERIMENTS (scripts/build_variants.sh) swaps the
+// empty hook object for scripts/experiments/bh_engine_hooks.hpp (the per-wave timeline and clock stamps of the walk).
+#ifdef BHGPU_EXPERIMENTS
+#include "../../scripts/experiments/bh_engine_hooks.hpp"
+#else
+struct ExpHooks {
+    hipError_t create(int64_t) { return hipSuccess; }
+    void walk_args(WalkFastArgs &) const {}
+    void destroy(int64_t) {}
+};
+#endif
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -56,7 +68,6 @@ struct bh_ctx {
     int64_t samples_n = -1;        // spos holds the sorted positions of a build of this many bodies (-1: none)
     uint64_t *splitters = nullptr;
     uint16_t *sort_dig = nullptr;  // bucket of every key (written by the histogram, read by the scatter)
-    bool sort_wave_rank = true;    // radix_scatter_w (wave-private ranking); experiments: BH_SORT_WAVE_RANK=0
     int build_items = 0;           // 0 = automatic, else keys per thread in the sort / scan kernels (2, 4, 8)
     bool hilbert = false;                // fp32 mode: Hilbert-ordered keys (BH_HILBERT=0 disables, A/B)
     int partial_count = 0;         // > 0: partial[] holds per-workgroup min/max of the current positions
@@ -84,11 +95,6 @@ struct bh_ctx {
     uint64_t *keys_sorted = nullptr;
     uint32_t *perm = nullptr;
     uint32_t *radix_counts = nullptr, *bsum_sort = nullptr, *bsum_u32 = nullptr, *cnt = nullptr;
-#ifdef BHGPU_EXPERIMENTS
-    uint32_t *os_ghist = nullptr, *os_status = nullptr, *os_counter = nullptr, *os_err = nullptr;   // onesweep
-    int64_t os_status_words = 0;
-#endif
-    bool sort_onesweep = false;          // experiments: BH_SORT_ONESWEEP=1 selects the look-back sort
     uint64_t *coarse = nullptr;          // fp32: every 256th sorted key
     uint32_t *cell_first = nullptr;      // fp32: rank of a subdivided cell -> its first sorted body
     d3 *terms = nullptr, *bsum_d3 = nullptr;
@@ -125,9 +131,7 @@ struct bh_ctx {
     bool sort_pack = true;              // BH_SORT_PACK=0: separate key and index arrays in every pass (A/B)
     unsigned long long *orb_hist = nullptr;
     double *mig_send = nullptr, *mig_recv = nullptr;
-#ifdef BHGPU_EXPERIMENTS
-    uint64_t *timeline = nullptr;       // BH_WALK_TIMELINE=path: per-wave timestamps of the last walk, dumped by bh_destroy
-#endif
+    ExpHooks exp;                       // A/B builds only (-DBHGPU_EXPERIMENTS); an empty struct in the product
 
     // measurement
     std::vector<hipEvent_t> ev;        // pairs around the walk kernel, one pair per step
@@ -275,10 +279,7 @@ int enqueue_build_t(bh_ctx *c)
     if (n > 0) {
         // 2. keys by fp64 bisection, 3. stable radix sort
         // keys of <= 40 bits for <= 2^24 bodies carry the body index in the key word through the sort
-        const bool pack = Dm >= 1 && 2 * Dm <= kPackShift && n <= ((int64_t)1 << (64 - kPackShift)) && c->sort_wave_rank
-#ifdef BHGPU_EXPERIMENTS
-                          && !c->sort_onesweep
-#endif
+        const bool pack = Dm >= 1 && 2 * Dm <= kPackShift && n <= ((int64_t)1 << (64 - kPackShift))
                           && c->sort_pack;
         // bucket sort (bh_sort.hpp): one counting pass by splitters from the previous build + one in-LDS sort per bucket
         // (exact modes and BH_HILBERT=0 too since round 3: the splitters only have to be sorted, whatever curve the keys follow)
@@ -313,23 +314,6 @@ int enqueue_build_t(bh_ctx *c)
         if (c->time_groups) (void)hipEventRecord(c->ev_grp[0], st);
         const unsigned nbl = blocks_for(n, ITEMS == kItems ? kSortTile : TILE);
         int cur = 0;
-#ifdef BHGPU_EXPERIMENTS
-        if (c->sort_onesweep && c->sort_passes > 0) {
-            const int P = c->sort_passes;
-            const int64_t words = (int64_t)P * nbl * kRadix;
-            hipLaunchKernelGGL(radix_zero, dim3(std::min<unsigned>(1024, blocks_for(words, kBlock))), dim3(kBlock), 0, st,
-                               c->os_ghist, c->os_status, words, c->os_counter);
-            hipLaunchKernelGGL(radix_hist_all, dim3(std::min<unsigned>(512, nbl)), dim3(kBlock), 0, st, c->keys[0], n, P,
-                               c->os_ghist, c->os_status, words, c->os_counter);
-            for (int p = 0; p < P; ++p) {
-                hipLaunchKernelGGL(radix_onesweep, dim3(nbl), dim3(kBlock), 0, st, c->keys[cur], c->vals[cur],
-                                   c->keys[cur ^ 1], c->vals[cur ^ 1], c->os_ghist + p * kRadix,
-                                   c->os_status + (int64_t)p * nbl * kRadix, c->os_counter + p, c->os_err, n,
-                                   p * kRadixBits);
-                cur ^= 1;
-            }
-        } else
-#endif
         if (bucket) {
             constexpr int SI = (ITEMS == kItems ? kSortItems : ITEMS);
             auto pass = [&](auto bits_tag) {
@@ -353,8 +337,8 @@ int enqueue_build_t(bh_ctx *c)
             hipLaunchKernelGGL(bucket_sort_kernel, dim3(nb), dim3(kBsThreads), 0, st, c->keys[1], c->keys[0], c->vals[0],
                                c->bsum_sort, c->bsum_sort + kBucketStartOffset, &c->ctr->sort_spills, &c->ctr->sort_reruns);
             cur = 0;
-        } else if (c->sort_wave_rank) {
-            // default: kSortBits-wide digits, wave-private ranking, digit-sorted write-out
+        } else {
+            // kSortBits-wide digits, wave-private ranking, digit-sorted write-out
             constexpr int SB = kSortBits, SR = 1 << SB, SI = (ITEMS == kItems ? kSortItems : ITEMS);
             const int passes = (2 * Dm + SB - 1) / SB;
             for (int p = 0; p < passes; ++p) {
@@ -375,20 +359,6 @@ int enqueue_build_t(bh_ctx *c)
                 cur ^= 1;
             }
         }
-#ifdef BHGPU_EXPERIMENTS
-        else
-        for (int p = 0; p < c->sort_passes; ++p) {
-            const int shift = p * kRadixBits;
-            hipLaunchKernelGGL((radix_hist<ITEMS == kItems ? kSortItems : ITEMS>), dim3(nbl), dim3(kBlock), 0, st,
-                               c->keys[cur], c->radix_counts, n, shift, (int)nbl);
-            hipLaunchKernelGGL(radix_rowscan, dim3(kRadix), dim3(kBlock), 0, st, c->radix_counts, c->bsum_sort,
-                               (int)nbl);
-            hipLaunchKernelGGL((radix_scatter<ITEMS == kItems ? kSortItems : ITEMS>), dim3(nbl), dim3(kBlock), 0, st,
-                               c->keys[cur], c->vals[cur], c->keys[cur ^ 1], c->vals[cur ^ 1], c->radix_counts,
-                               c->bsum_sort, n, shift, (int)nbl);
-            cur ^= 1;
-        }
-#endif
         c->keys_sorted = c->keys[cur];
         c->perm = c->vals[cur];
         if constexpr (!EXACT) {
@@ -487,7 +457,7 @@ int enqueue_build(bh_ctx *c)
     // workgroups, fewer sequential rounds in each); BH_BUILD_ITEMS = 2, 4 or 8 overrides
     int items = c->build_items;
     if (items == 0) items = c->n <= kSmallBuildBodies ? 2 : c->n <= kMediumBuildBodies ? 4 : 8;
-    if (c->sort_onesweep || c->n > (1 << 22)) items = 8;         // (scratch for small tiles is sized for 4M bodies)
+    if (c->n > (1 << 22)) items = 8;         // (scratch for small tiles is sized for 4M bodies)
     switch (items) {
     case 2: return enqueue_build_items<2>(c);
     case 4: return enqueue_build_items<4>(c);
@@ -586,9 +556,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         a.n_trees = c->let_mode ? c->world : 0; a.self_rank = c->let_mode ? c->rank : -1;
         a.part = part; a.acc_part = c->acc_part;
         a.forest_base = c->forest_base; a.let_cap = c->let_cap;
-#ifdef BHGPU_EXPERIMENTS
-        a.timeline = c->timeline;
-#endif
+        c->exp.walk_args(a);
         a.group_cost = (lo == 0 && hi == c->n) ? c->group_cost : nullptr;
         a.bucket_consts = c->walk_consts;
         a.body_counts = nullptr;
@@ -642,14 +610,7 @@ int check_overflow(bh_ctx *c)
 {
     TreeCounters h{};
     BH_HIP(c, hipMemcpyAsync(&h, c->ctr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-#ifdef BHGPU_EXPERIMENTS
-    uint32_t sort_err = 0;
-    BH_HIP(c, hipMemcpyAsync(&sort_err, c->os_err, sizeof(sort_err), hipMemcpyDeviceToHost, c->stream));
-#endif
     BH_HIP(c, hipStreamSynchronize(c->stream));
-#ifdef BHGPU_EXPERIMENTS
-    if (sort_err) return fail(c, BH_ERR_DEVICE, "radix sort look-back timed out (inter-workgroup wait exceeded its bound)");
-#endif
     if (h.overflow || (int64_t)h.n_internal > c->internal_cap)
         return fail(c, BH_ERR_CAPACITY, "tree needs " + std::to_string(1 + 4 * (int64_t)h.n_internal) +
                                         " nodes, node_capacity is " + std::to_string(c->node_cap));
@@ -700,11 +661,6 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     c->compat = cfg->reference_compat != 0;
     c->device = cfg->device;
     c->sort_passes = (2 * c->Dm + kRadixBits - 1) / kRadixBits;
-#ifdef BHGPU_EXPERIMENTS
-    // measured-and-rejected variants: present only in scripts/ A/B builds
-    if (const char *e = std::getenv("BH_SORT_WAVE_RANK")) c->sort_wave_rank = std::atoi(e) != 0;
-    if (const char *e = std::getenv("BH_SORT_ONESWEEP")) c->sort_onesweep = std::atoi(e) != 0;
-#endif
     if (const char *e = std::getenv("BH_WALK_SPLIT")) c->walk_split = std::atoi(e);
     if (const char *e = std::getenv("BH_WALK_ASM")) c->walk_asm = std::atoi(e) != 0;
     if (const char *e = std::getenv("BH_SORT_PACK")) c->sort_pack = std::atoi(e) != 0;
@@ -756,11 +712,6 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
       A(&c->bsum_sort, 2 * kBucketStartOffset);               // bucket totals, then bucket starts
       A(&c->splitters, kBucketsBig);
       A(&c->sort_dig, (size_t)std::min<int64_t>(cap, kBucketMaxNBig) + 16);
-#ifdef BHGPU_EXPERIMENTS
-      c->os_status_words = (int64_t)kMaxPasses * nbl * kRadix;
-      A(&c->os_status, c->os_status_words); A(&c->os_ghist, kMaxPasses * kRadix); A(&c->os_counter, kMaxPasses);
-      A(&c->os_err, 4);
-#endif
     }
     A(&c->bsum_u32, std::max<size_t>(blocks_for(cap + 1, kTile), blocks_for(std::min<int64_t>(cap, 1 << 22) + 1, kBlock * kSmallItems)) + 8);
     A(&c->partial, 4 * (std::max<size_t>(1024, blocks_for(cap, kWave)) + 2)); A(&c->box, 8); A(&c->bslots, 4 * kBoundSlots);
@@ -783,16 +734,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
         const void *wc[4] = {c->aux, c->spos, c->smass, nullptr};
         if (hipMemcpy(c->walk_consts, wc, sizeof(wc), hipMemcpyHostToDevice) != hipSuccess) { c->err = "hipMemcpy failed"; return bail(BH_ERR_DEVICE); }
     }
-#ifdef BHGPU_EXPERIMENTS
-    if (std::getenv("BH_WALK_TIMELINE") && !c->exact) {
-        rc = dev_alloc(c, &c->timeline, 4 * (size_t)(cap / kWave + 8));
-        if (rc) return bail(rc);
-        (void)hipMemset(c->timeline, 0, 4 * (size_t)(cap / kWave + 8) * sizeof(uint64_t));
-    }
-#endif
-#ifdef BHGPU_EXPERIMENTS
-    if (hipMemset(c->os_err, 0, 16) != hipSuccess) { c->err = "hipMemset failed"; return bail(BH_ERR_DEVICE); }
-#endif
+    if (!c->exact && c->exp.create(cap) != hipSuccess) { c->err = "experiment hooks: allocation failed"; return bail(BH_ERR_DEVICE); }
     for (auto &e : c->ev_step) if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(BH_ERR_DEVICE); }
     for (auto &e : c->ev_build) if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(BH_ERR_DEVICE); }
     for (auto &e : c->ev_grp) if (hipEventCreate(&e) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(BH_ERR_DEVICE); }
@@ -806,15 +748,7 @@ void bh_destroy(bh_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-#ifdef BHGPU_EXPERIMENTS
-    if (c->timeline) {
-        const size_t words = 4 * (size_t)((c->n + kWave - 1) / kWave);
-        std::vector<uint64_t> h(words);
-        if (hipMemcpy(h.data(), c->timeline, words * sizeof(uint64_t), hipMemcpyDeviceToHost) == hipSuccess) {
-            if (FILE *fp = std::fopen(std::getenv("BH_WALK_TIMELINE"), "wb")) { std::fwrite(h.data(), 8, words, fp); std::fclose(fp); }
-        }
-    }
-#endif
+    c->exp.destroy(c->n);
     for (void *p : c->allocs) (void)hipFree(p);
     for (auto e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev_step) if (e) (void)hipEventDestroy(e);

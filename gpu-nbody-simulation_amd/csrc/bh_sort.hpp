@@ -13,9 +13,8 @@
 //     bucket_sort_kernel : one workgroup sorts one bucket entirely in LDS.
 //
 // Element order inside a tile is (wave, round, lane) = tile order and ranks follow lane order, so equal keys
-// keep their input order.  Measured-and-rejected variants (the barrier-per-round scatter, the look-back
-// "onesweep" sort) live in scripts/experiments/bh_sort_experiments.hpp, included by -DBHGPU_EXPERIMENTS builds only.  (Also rejected
-// in round 1: letting every scatter workgroup derive its own offsets from the count matrix -- it re-reads the
+// keep their input order.  (Measured and rejected in rounds 1-2, code removed in round 4: a barrier-per-round scatter and
+// a look-back "onesweep" sort -- DESIGN.md section 3, profiles/r02_final; also letting every scatter workgroup derive its own offsets from the count matrix -- it re-reads the
 // 256 x nblocks matrix per workgroup, 37 us per pass at N = 1M against 18 + 14 us for scatter + scan then.)
 #pragma once
 
@@ -702,7 +701,3 @@ __global__ __launch_bounds__(kBsThreads) void bucket_sort_kernel(uint64_t *__res
 
 
 }  // namespace bh
-
-#ifdef BHGPU_EXPERIMENTS   // measured-and-rejected variants, scripts/ A/B builds only
-#include "../../scripts/experiments/bh_sort_experiments.hpp"
-#endif

@@ -931,9 +931,6 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
         wkeys[k] = (j >= 0 && j < n) ? keys[j] : 0ull;
     }
     __syncthreads();
-#if defined(BHGPU_EXPERIMENTS) && defined(BH_NODES_EXPT2)
-    if (BH_NODES_EXPT2 == 1) return;                            // timing experiment: launch + window only
-#endif
     // (a select between the two pointers compiles to ONE flat load from a generic address -- through the vector memory
     // path even when the address is in LDS, with 64-bit address arithmetic; almost every read is inside the window, so
     // the window is read with a plain LDS instruction and the rare lane outside it is patched up under a uniform test)
@@ -1036,11 +1033,6 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     const int sh = 2 * (Dm - d);
     const uint64_t pfx = (d == 0) ? 0ull : (key >> sh);
     int32_t e;
-#if defined(BHGPU_EXPERIMENTS) && defined(BH_NODES_EXPT)
-    const bool expt_skip = d < BH_NODES_EXPT;                   // timing experiment: cells above this depth skip their searches
-#else
-    constexpr bool expt_skip = false;
-#endif
     // Most cells hold a handful of bodies: the next eight keys, read in one round, settle the end AND the three
     // child boundaries of every cell of at most eight bodies without a loop (the searches below are divergent
     // per-lane loops of dependent LDS reads; a wave is as slow as its largest cell, but it no longer also pays
@@ -1049,7 +1041,6 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     bool have_bnd = false;
     const int shc = sh - 2;
     if (d == 0) e = n;
-    else if (expt_skip) e = i + 1;
     else {
         const uint64_t cell_hi = (pfx + 1) << sh;                // keys are sorted: outside the cell <=> key >= cell_hi
         uint64_t nk[8];
@@ -1084,7 +1075,7 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
             have_bnd = true;
         }
     }
-    if (d != 0 && !expt_skip && !have_bnd) {                     // nine bodies or more: galloping, then bisection
+    if (d != 0 && !have_bnd) {                     // nine bodies or more: galloping, then bisection
         int32_t a = i + 8, step = 8, b;
         for (;;) {
             b = (step > n - a) ? n : a + step;                   // no 32-bit overflow
@@ -1120,8 +1111,7 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
     const bool cells_in_window = __ballot(!(i - 1 >= wlo && e - wlo <= kKeyWin)) == 0ull;   // uniform
     if (!have_bnd) {
         const uint64_t tg[3] = {(pfx << 2) | 1ull, (pfx << 2) | 2ull, (pfx << 2) | 3ull};
-        if (expt_skip) bnd[1] = bnd[2] = bnd[3] = e;
-        else if (cells_in_window) {
+        if (cells_in_window) {
             // branch-free bisection of the three child boundaries inside the window: every round reads one key per
             // boundary whether or not that search is still open (a closed one re-reads its end point: at worst entry
             // kKeyWin, inside the LDS block) and moves its bounds by selects -- the guarded form above compiles to
@@ -1152,9 +1142,6 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
         bool left = c > 0 && bnd[c] - bnd[c - 1] > 1, right = c < 4 && bnd[c + 1] - bnd[c] > 1;
-#if defined(BHGPU_EXPERIMENTS) && defined(BH_NODES_EXPT2)
-        if (BH_NODES_EXPT2 == 2) left = right = false;          // timing experiment: no prefix-sum gathers
-#endif
         ps[c] = (left || right) ? psum[bnd[c]] : d3{1.0, 1.0, 1.0};
     }
 #pragma unroll
@@ -1225,9 +1212,6 @@ __global__ __launch_bounds__(kBlock, 5) void nodes_fast_kernel(
         typedef int32_t v4 __attribute__((ext_vector_type(4)));
         v4 *dq = reinterpret_cast<v4 *>(qi + ((int64_t)r_block + 1) * 20);
         const v4 *sq = reinterpret_cast<const v4 *>(stage_q);
-#if defined(BHGPU_EXPERIMENTS) && defined(BH_NODES_EXPT2)
-        if (BH_NODES_EXPT2 != 3)                                // timing experiment: no quad stores
-#endif
         for (uint32_t k = threadIdx.x; k < cells * 5; k += kBlock) dq[k] = sq[k];
         if (FULL_AUX) {
             v4 *da = reinterpret_cast<v4 *>(aux + 4 * ((int64_t)r_block + 1));

@@ -33,7 +33,7 @@ struct WalkFastArgs {
     uint32_t *group_cost;          // per 64-body group: loop iterations of its walk (load-balancing weight), may be null
     int32_t pair_limit;            // one-wave walk: two stack entries per iteration while sp <= pair_limit
                                    // (116 - 3 * (max_depth - 1), never negative: the 128-entry stack bound, bh_walk_fast.hip)
-    uint64_t *timeline;            // -DBHGPU_EXPERIMENTS builds: per-wave {start, end, hw id, cost} (scripts/walk_timeline.py)
+    uint64_t *timeline;            // -DBHGPU_EXPERIMENTS builds: per-wave {start, end, hw id, cost, clock start, clock end} (scripts/walk_timeline.py)
     // forest walk (distributed step): besides the local tree (root quad 0) the bodies walk the
     // locally-essential trees received from the peers, whose root quads sit at
     // forest_base + t * let_cap for every t != self_rank, t < n_trees.  n_trees == 0: local tree only.

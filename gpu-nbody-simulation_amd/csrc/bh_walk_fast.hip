@@ -328,6 +328,60 @@ __device__ __forceinline__ QuadRegs load_quad(const QuadF BH_CONSTANT *q)
     BH_PUSH_HI("s64", "s24", "s25", SFX "B0t") BH_PUSH_HI("s65", "s24", "s25", SFX "B1t")          \
     BH_PUSH_HI("s66", "s24", "s25", SFX "B2t") BH_PUSH_HI("s67", "s24", "s25", SFX "B3t")
 
+// (the loop proper, shared by walk_tree_asm and walk_tree_asm_y: LIMITCHK is empty, or the iteration limit of the latter)
+#define BH_TREE_LOOP(LIMITCHK) \
+    /* ---------------------------------------------------------------- next entries */ \
+    "Lloop_%=:\n" \
+    "s_add_u32 %[cost], %[cost], 1\n" \
+    BH_LOOP_GUARD LIMITCHK \
+    "s_setprio 2\n" \
+    "s_cmp_gt_u32 m0, 56\n" \
+    "s_cbranch_scc1 LloopChk_%=\n" \
+    BH_ITERATION("F", BH_POP_FAST("s68", "s44", "s45"), BH_POP_FAST("s70", "s46", "s47"), BH_NOCHK) \
+    "LloopChk_%=:\n" /* more than 56 entries: pushes / pops pick their VGPRs */ \
+    BH_ITERATION("C", BH_POP("s68", "s44", "s45", "A"), BH_POP("s70", "s46", "s47", "B"), BH_PUSHCHK) \
+    BH_HI_STUBS("C") \
+    BH_POP_HI("s68", "s44", "s45", "A") \
+    BH_POP_HI("s70", "s46", "s47", "B") \
+    /* ---- bucket reference -(node id) - 2: the cell's bodies one by one for the lanes that reached it */ \
+    /* (self and exactly coincident bodies contribute nothing: d2 > 0 fails); -1 is dropped. */ \
+    /* NB (s70, s[46:47]) is preserved; s72 is -1 here. */ \
+    "Lspecial_%=:\n" \
+    "s_cmp_eq_u32 s68, -1\n" \
+    "s_cbranch_scc1 Lloop_%=\n" \
+    "s_load_dwordx8 s[56:63], %[consts], 0x0\n" /* {aux, sorted positions, sorted masses}: this path only */ \
+    "s_sub_i32 s68, -2, s68\n" \
+    "s_lshl_b32 s69, s68, 3\n" \
+    "s_mov_b64 exec, s[44:45]\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "s_load_dwordx2 s[48:49], s[56:57], s69\n" /* {first sorted body, count} */ \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "s_cmp_lt_i32 s49, 1\n" \
+    "s_cbranch_scc1 Lloop_%=\n" \
+    "s_add_u32 s49, s48, s49\n" \
+    "Lbody_%=:\n" \
+    "s_lshl_b32 s69, s48, 3\n" \
+    "s_load_dwordx2 s[50:51], s[58:59], s69\n" \
+    "s_lshl_b32 s69, s48, 2\n" \
+    "s_load_dword s52, s[60:61], s69\n" \
+    "s_add_u32 s48, s48, 1\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "v_pk_add_f32 v[22:23], s[50:51], v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n" \
+    "s_cmp_lt_u32 s48, s49\n" /* loop condition (and the packed result's wait state) */ \
+    "v_mul_f32_e32 v24, v23, v23\n" \
+    "v_fmac_f32_e32 v24, v22, v22\n" \
+    "v_cmpx_lt_f32_e32 vcc, 0, v24\n" \
+    "v_rsq_f32_e32 v25, v24\n" \
+    "s_nop 0\n" /* wait state between v_rsq and its use */ \
+    "v_mul_f32_e32 v26, s52, v25\n" \
+    "v_mul_f32_e32 v26, v25, v26\n" \
+    "v_mul_f32_e32 v24, v25, v26\n" \
+    "v_fmac_f32_e32 v28, v24, v22\n" \
+    "v_fmac_f32_e32 v29, v24, v23\n" \
+    "s_mov_b64 exec, s[44:45]\n" \
+    "s_cbranch_scc1 Lbody_%=\n" \
+    "s_branch Lloop_%=\n"
+
 __device__ __forceinline__ uint32_t walk_tree_asm(const QuadF BH_CONSTANT *quads, const void BH_CONSTANT *consts,
                                                    int32_t root, uint64_t everyone, int32_t pair_limit, float px,
                                                    float py, float &ax, float &ay)
@@ -343,57 +397,7 @@ __device__ __forceinline__ uint32_t walk_tree_asm(const QuadF BH_CONSTANT *quads
         "s_mov_b32 s72, -1\n"                                   // no NA
         "s_mov_b32 %[cost], 1\n"                                // loop iterations: the group's cost (re-balancing weight)
         "s_branch LArF_%=\n"                                    // the root quad alone
-        // ---------------------------------------------------------------- next entries
-        "Lloop_%=:\n"
-        "s_add_u32 %[cost], %[cost], 1\n"
-        BH_LOOP_GUARD
-        "s_setprio 2\n"
-        "s_cmp_gt_u32 m0, 56\n"
-        "s_cbranch_scc1 LloopChk_%=\n"
-        BH_ITERATION("F", BH_POP_FAST("s68", "s44", "s45"), BH_POP_FAST("s70", "s46", "s47"), BH_NOCHK)
-        "LloopChk_%=:\n"                                        // more than 56 entries: pushes / pops pick their VGPRs
-        BH_ITERATION("C", BH_POP("s68", "s44", "s45", "A"), BH_POP("s70", "s46", "s47", "B"), BH_PUSHCHK)
-        BH_HI_STUBS("C")
-        BH_POP_HI("s68", "s44", "s45", "A")
-        BH_POP_HI("s70", "s46", "s47", "B")
-        // ---- bucket reference -(node id) - 2: the cell's bodies one by one for the lanes that reached it
-        //      (self and exactly coincident bodies contribute nothing: d2 > 0 fails); -1 is dropped.
-        //      NB (s70, s[46:47]) is preserved; s72 is -1 here.
-        "Lspecial_%=:\n"
-        "s_cmp_eq_u32 s68, -1\n"
-        "s_cbranch_scc1 Lloop_%=\n"
-        "s_load_dwordx8 s[56:63], %[consts], 0x0\n"              // {aux, sorted positions, sorted masses}: this path only
-        "s_sub_i32 s68, -2, s68\n"
-        "s_lshl_b32 s69, s68, 3\n"
-        "s_mov_b64 exec, s[44:45]\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_load_dwordx2 s[48:49], s[56:57], s69\n"              // {first sorted body, count}
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_cmp_lt_i32 s49, 1\n"
-        "s_cbranch_scc1 Lloop_%=\n"
-        "s_add_u32 s49, s48, s49\n"
-        "Lbody_%=:\n"
-        "s_lshl_b32 s69, s48, 3\n"
-        "s_load_dwordx2 s[50:51], s[58:59], s69\n"
-        "s_lshl_b32 s69, s48, 2\n"
-        "s_load_dword s52, s[60:61], s69\n"
-        "s_add_u32 s48, s48, 1\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_pk_add_f32 v[22:23], s[50:51], v[20:21] neg_lo:[0,1] neg_hi:[0,1]\n"
-        "s_cmp_lt_u32 s48, s49\n"                         // loop condition (and the packed result's wait state)
-        "v_mul_f32_e32 v24, v23, v23\n"
-        "v_fmac_f32_e32 v24, v22, v22\n"
-        "v_cmpx_lt_f32_e32 vcc, 0, v24\n"
-        "v_rsq_f32_e32 v25, v24\n"
-        "s_nop 0\n"                                             // wait state between v_rsq and its use
-        "v_mul_f32_e32 v26, s52, v25\n"
-        "v_mul_f32_e32 v26, v25, v26\n"
-        "v_mul_f32_e32 v24, v25, v26\n"
-        "v_fmac_f32_e32 v28, v24, v22\n"
-        "v_fmac_f32_e32 v29, v24, v23\n"
-        "s_mov_b64 exec, s[44:45]\n"
-        "s_cbranch_scc1 Lbody_%=\n"
-        "s_branch Lloop_%=\n"
+        BH_TREE_LOOP("")
         "Ldone_%=:\n"
         "s_setprio 0\n"
         "s_mov_b64 exec, -1\n"                                  // (the kernel runs the traversal with all lanes enabled)
@@ -550,6 +554,7 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
     if (a.ctr->overflow) return;
 #ifdef BHGPU_EXPERIMENTS
     const uint64_t dbg_t0 = a.timeline ? __builtin_amdgcn_s_memrealtime() : 0;     // 100 MHz wall clock
+    const uint64_t dbg_c0 = a.timeline ? __builtin_amdgcn_s_memtime() : 0;         // shader clock cycles
 #endif
     // Workgroup -> group of bodies: dispatch order.  (Measured and rejected, rounds 1-3: an XCD-contiguous placement --
     // XCD x takes the x-th contiguous eighth of the sorted order -- halves the L2 misses of the launch, 1.61 M -> 0.81 M,
@@ -917,12 +922,15 @@ __global__ __launch_bounds__(SPLIT > 1 ? kWave * SPLIT : kBlock) void walk_fast_
         }
     } else if (e.partial) block_bounds_to_partial(valid, bx, by, e.partial + 4 * (size_t)lb, e.slots);
 #ifdef BHGPU_EXPERIMENTS
-    if (e.timeline && lane == 0) {                              // per wave: start, end (10 ns ticks), hardware id, cost
+    if (e.timeline && lane == 0) {                              // per wave: start, end (10 ns ticks), hardware id, cost, clock stamps
         const int64_t wv = (int64_t)blockIdx.x * (blockDim.x >> 6) + w;
-        e.timeline[4 * wv + 0] = dbg_t0;
-        e.timeline[4 * wv + 1] = __builtin_amdgcn_s_memrealtime();
-        e.timeline[4 * wv + 2] = (uint64_t)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
-        e.timeline[4 * wv + 3] = cost;
+        const uint64_t c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+        e.timeline[6 * wv + 0] = dbg_t0;
+        e.timeline[6 * wv + 1] = t1;
+        e.timeline[6 * wv + 2] = (uint64_t)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        e.timeline[6 * wv + 3] = cost;
+        e.timeline[6 * wv + 4] = dbg_c0;
+        e.timeline[6 * wv + 5] = c1;
     }
 #endif
     if (e.group_cost && lane == 0 && (SPLIT == 1 || w == 0)) {

@@ -1,23 +1,45 @@
 """Per-wave timeline of the last walk launch (experiments build, BH_WALK_TIMELINE): how full are the wave
 slots over the launch, how long is the tail, how do wave durations spread?
-  BHGPU_LIB_OPT_IN=1 BHGPU_LIB=.../libbhgpu_exp.so BH_WALK_TIMELINE=/tmp/tl.bin python scripts/walk_timeline.py [n] [init]"""
+And the IN-KERNEL CLOCK of the walk (VERDICT r3 #2a; MI355X_MICROARCH.md, DVFS give-back item 6): per wave
+delta s_memtime / delta s_memrealtime x 100 MHz, median over the waves of the LAST walk after `steps` back-to-back steps
+(>= 2 s of launches).  Writes profiles-ready JSON when --json PATH is given.
+  BHGPU_LIB_OPT_IN=1 BHGPU_LIB=.../libbhgpu_exp.so BH_WALK_TIMELINE=/tmp/tl.bin python scripts/walk_timeline.py [n] [init] [theta] [f32|mixed] [steps] [--json PATH]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import gpu_nbody_simulation_amd as G
 from gpu_nbody_simulation_amd import initial_conditions as IC
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
-kind = sys.argv[2] if len(sys.argv) > 2 else "plummer"
+import json
+argv = [x for x in sys.argv[1:] if not x.startswith("--")]
+jpath = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+if jpath: argv.remove(jpath)
+n = int(argv[0]) if len(argv) > 0 else 1 << 20
+kind = argv[1] if len(argv) > 1 else "plummer"
+theta = float(argv[2]) if len(argv) > 2 else 0.5
+prec = G.Precision.MIXED if len(argv) > 3 and argv[3] == "mixed" else G.Precision.F32
+steps = int(argv[4]) if len(argv) > 4 else 5
 path = os.environ["BH_WALK_TIMELINE"]
 m, p, v = IC.make(kind, n, 1, quasi_static=True)
-with G.BarnesHutEngine(G.BhConfig(capacity=n, theta=0.5, max_depth=21, precision=G.Precision.F32, reference_compat=False)) as e:
+with G.BarnesHutEngine(G.BhConfig(capacity=n, theta=theta, max_depth=21, precision=prec, reference_compat=False)) as e:
     e.upload(p, v, m)
-    e.step(5)
+    e.step(steps)
     e.sync()
     st = e.stats()
-t = np.fromfile(path, dtype=np.uint64).reshape(-1, 4)
+    info = e.build_info()
+t = np.fromfile(path, dtype=np.uint64).reshape(-1, 6)
 start, end, hw, cost = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64), t[:, 2], t[:, 3].astype(np.int64)
+clk = (t[:, 5].astype(np.int64) - t[:, 4].astype(np.int64)) / np.maximum(end - start, 1) * 100e6     # Hz, per wave
+long_enough = (end - start) > 2000                                                               # > 20 us: stamp granularity
+print(f"in-kernel clock (delta s_memtime / delta s_memrealtime x 100 MHz), waves longer than 20 us: median {np.median(clk[long_enough])/1e9:.4f} GHz  "
+      f"p10 {np.percentile(clk[long_enough],10)/1e9:.4f}  p90 {np.percentile(clk[long_enough],90)/1e9:.4f}  ({int(long_enough.sum())} waves, after {steps} steps)")
+if jpath:
+    from gpu_nbody_simulation_amd.build import source_digest
+    json.dump({"kernel": "walk_fast_kernel", "workload": f"{kind}_N{n}_theta{theta}", "clock_hz_median": float(np.median(clk[long_enough])),
+               "clock_hz_p10": float(np.percentile(clk[long_enough], 10)), "clock_hz_p90": float(np.percentile(clk[long_enough], 90)),
+               "waves": int(long_enough.sum()), "steps_before_the_stamped_launch": steps, "walk_ms_events": st.walk_ms,
+               "method": "per wave: delta s_memtime / delta s_memrealtime x 100 MHz; experiments build of the same sources",
+               "library": info, "source_digest": source_digest()}, open(jpath, "w"), indent=1)
 t0, t1 = start.min(), end.max()
 dur = (end - start) * 10.0                      # ns
 span = (t1 - t0) * 10.0
