@@ -1,7 +1,7 @@
 """Measured fp32 / mixed-precision parity of the walk against the oracle, body by body, split by whether the oracle
 finds a BORDERLINE cell for the body (tests/parity_classes.py).  One JSON line per configuration; the tolerances of
 tests/test_gpu_parity_classes.py and tests/test_gpu_configs.py are <= 2x these measurements.
-    python scripts/parity_measure.py [c2 c2p c3 c3u c4 c5]"""
+    python scripts/parity_measure.py [c2 c2p c3 c3u c4 c5 t3um@1 ... ]      (name@seed: another seed of a configuration)"""
 import dataclasses
 import json
 import os
@@ -25,8 +25,8 @@ CONFIGS = {
     "c2p": ("plummer", 65536, 0.5, "f32", 0),
     "c3": ("plummer", 1 << 20, 0.5, "f32", 0),
     "c3u": ("uniform", 1 << 20, 0.5, "f32", 0),
-    "c4": ("plummer", 1 << 22, 0.5, "f32", 65536),
-    "c5": ("plummer", 1 << 24, 0.3, "mixed", 65536),
+    "c4": ("plummer", 1 << 22, 0.5, "f32", 0),                 # round 4: ALL 4,194,304 bodies (round 3: 65,536)
+    "c5": ("plummer", 1 << 24, 0.3, "mixed", 1 << 20),         # round 4: 1,048,576 sampled bodies (round 3: 65,536)
     # tests/test_gpu_configs.py::test_theta_03_without_compat_against_the_uncapped_oracle (seed 7 there, 1 here)
     "t3u": ("uniform", 65536, 0.3, "f32", 0), "t3p": ("plummer", 65536, 0.3, "f32", 0),
     "t3um": ("uniform", 65536, 0.3, "mixed", 0), "t3pm": ("plummer", 65536, 0.3, "mixed", 0),
@@ -34,10 +34,12 @@ CONFIGS = {
 
 
 def measure(name):
+    name, _, seed = name.partition("@")
+    seed = int(seed or 1)
     kind, n, theta, prec, sample = CONFIGS[name]
-    m, p, v = IC.make(kind, n, 1, quasi_static=True)
+    m, p, v = IC.make(kind, n, seed, quasi_static=True)
     if prec == "mixed":                                   # fp64 positions that are NOT fp32 values (config 5)
-        p = p * (1.0 + 3e-9 * np.random.default_rng(1).standard_normal(p.shape))
+        p = p * (1.0 + 3e-9 * np.random.default_rng(seed).standard_normal(p.shape))
     m, p, v, s = PC.sample_first(m, p, v, sample or n)
     t0 = time.time()
     with G.BarnesHutEngine(G.BhConfig(capacity=n, theta=theta, max_depth=21, reference_compat=False, flags=FLAG_WALK_STATS,
@@ -51,7 +53,7 @@ def measure(name):
     t2 = time.time()
     rep = PC.classify(a, cnt, m, p, theta, s, pos_rounded=(prec == "mixed"), tree=tree)
     t3 = time.time()
-    print(json.dumps({"config": name, "kind": kind, "n": n, "theta": theta, "precision": prec,
+    print(json.dumps({"config": name, "seed": seed, "kind": kind, "n": n, "theta": theta, "precision": prec,
                       "seconds": {"gpu": round(t1 - t0, 1), "oracle_tree": round(t2 - t1, 1), "oracle_walk": round(t3 - t2, 1)},
                       **dataclasses.asdict(rep)}), flush=True)
 
