@@ -1272,7 +1272,8 @@ __global__ __launch_bounds__(kBlock) void com_up_kernel(NodeD *__restrict__ gd, 
 // twenty launches of this one.  Same sums in the same order either way.  (Round 4 built the pass in 2-3 launches -- a block of
 // consecutive pre-order ranks holds whole subtrees, the cells it cannot finish are one chain of ancestors, lists of those chains
 // are finished over 64 x larger ranges per launch -- once as a separate kernel and once started inside nodes_exact_kernel:
-// 107 and 136 us against these 112, each bitwise equal; profiles/r04_f64/com_ab.txt says where the time went.)
+// 107 and 136 us against these 112, each bitwise equal; and two depths per launch, the shallower one recomputing its
+// subdivided children from the grandchildren: build 0.277 ms against 0.257.  profiles/r04_f64/com_ab.txt says where the time went.)
 __global__ __launch_bounds__(kBlock) void com_level_kernel(NodeD *__restrict__ gd, const int32_t *__restrict__ self_node,
                                                             const int32_t *__restrict__ cell_depth,
                                                             const TreeCounters *__restrict__ ctr, int64_t internal_cap,
@@ -1295,6 +1296,5 @@ __global__ __launch_bounds__(kBlock) void com_level_kernel(NodeD *__restrict__ g
     if (tot > 0.0) { sx /= tot; sy /= tot; }
     gd[node].cx = sx; gd[node].cy = sy; gd[node].m = tot;
 }
-
 
 }  // namespace bh
