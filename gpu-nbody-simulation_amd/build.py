@@ -37,7 +37,8 @@ def source_digest() -> str:
     (there is no .git on the GPU box)."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "bhgpu.h")]:
+    srcs = [f for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h")) and os.path.isfile(os.path.join(CSRC, f))]
+    for f in srcs + [os.path.join("..", "..", "include", "bhgpu.h")]:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
@@ -47,7 +48,7 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h"))] + [
         os.path.join(HERE, "..", "include", "bhgpu.h")]
     return any(os.path.getmtime(s) > t for s in srcs)
 

@@ -243,9 +243,23 @@ __device__ __forceinline__ uint64_t key_of_fast(double x, double y, double x0, d
         }
         return k;
     }
+    if (!HILBERT) {
+        // child-index order (the exact modes): digit = (x >= mid) | (y >= mid) << 1 per level, i.e. the bits of ix on the even
+        // and those of iy on the odd places of the key -- five shift-and-mask steps per axis instead of a loop over the levels
+        auto spread = [](uint32_t v) -> uint64_t {
+            uint64_t u = v;
+            u = (u | (u << 16)) & 0x0000FFFF0000FFFFull;
+            u = (u | (u << 8)) & 0x00FF00FF00FF00FFull;
+            u = (u | (u << 4)) & 0x0F0F0F0F0F0F0F0Full;
+            u = (u | (u << 2)) & 0x3333333333333333ull;
+            u = (u | (u << 1)) & 0x5555555555555555ull;
+            return u;
+        };
+        return spread(ix) | (spread(iy) << 1);
+    }
     for (; l >= 0; --l) {
         const int c = (int)(((ix >> l) & 1u) | (((iy >> l) & 1u) << 1));
-        k = (k << 2) | (uint64_t)(HILBERT ? hilbert_digit(state, c) : c);
+        k = (k << 2) | (uint64_t)hilbert_digit(state, c);
         state = hilbert_next(state, c);
     }
     return k;
@@ -389,9 +403,10 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const Real2 *__restrict__ 
     }
     const int64_t i = ((int64_t)blockIdx.x - nsb) * kBlock + threadIdx.x;
     if (i >= n) return;
-    const uint64_t k = HILBERT ? key_of_fast<HILBERT>((double)pos[i].x, (double)pos[i].y, x0, x1, y0, y1, Dm, bk4, bk5,
-                                                      bk6, bk7, s_hil3)
-                               : key_of<HILBERT>((double)pos[i].x, (double)pos[i].y, x0, x1, y0, y1, Dm);
+    // (round 4: the exact modes take the one-multiply look-up too -- the proof is about the bisection's comparisons, not about the
+    // order of the digits; bodies it cannot vouch for fall back to key_of, the reference's four-test DetermineChild)
+    const uint64_t k = key_of_fast<HILBERT>((double)pos[i].x, (double)pos[i].y, x0, x1, y0, y1, Dm, bk4, bk5, bk6, bk7,
+                                            HILBERT ? s_hil3 : nullptr);
     if (PACK) {
         keys[i] = k | ((uint64_t)i << kPackShift);
     } else {
