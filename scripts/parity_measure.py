@@ -27,6 +27,7 @@ CONFIGS = {
     "c3u": ("uniform", 1 << 20, 0.5, "f32", 0),
     "c4": ("plummer", 1 << 22, 0.5, "f32", 0),                 # round 4: ALL 4,194,304 bodies (round 3: 65,536)
     "c5": ("plummer", 1 << 24, 0.3, "mixed", 1 << 20),         # round 4: 1,048,576 sampled bodies (round 3: 65,536)
+    "c5all": ("plummer", 1 << 24, 0.3, "mixed", 0),            # every one of the 16,777,216 bodies
     # tests/test_gpu_configs.py::test_theta_03_without_compat_against_the_uncapped_oracle (seed 7 there, 1 here)
     "t3u": ("uniform", 65536, 0.3, "f32", 0), "t3p": ("plummer", 65536, 0.3, "f32", 0),
     "t3um": ("uniform", 65536, 0.3, "mixed", 0), "t3pm": ("plummer", 65536, 0.3, "mixed", 0),

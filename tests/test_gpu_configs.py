@@ -6,8 +6,8 @@
   C5: N = 16,777,216, theta = 0.3, fp64 positions / fp32 forces (BH_PRECISION_MIXED) -- the same two ways.
 
 Checked against the oracle (the CPU restatement of project.cu:575-675, uncapped tree, per-body MAC) -- round 4: on ALL
-4,194,304 bodies of C4 (5 s of oracle walk with 16 threads) and on 1,048,576 bodies of C5, a quarter from the core, a quarter
-from the halo, the rest a stride through the others (tests/parity_classes.py; round 3: 65,536 each) -- and BY CLASS: bodies whose walk meets no borderline acceptance criterion must accept
+4,194,304 bodies of C4 (5 s of oracle walk with 16 threads) and on ALL 16,777,216 bodies of C5 (55 s; round 3: 65,536 sampled
+bodies each, tests/parity_classes.py) -- and BY CLASS: bodies whose walk meets no borderline acceptance criterion must accept
 exactly the oracle's node set (equal per-body interaction counts) and differ by rounding only, inside tolerances
 <= 2x the measured values (TOL below); the others may differ by their flip budget.  Plus the size-independent
 properties: determinism, tree size = the oracle's depth-21 tree, Newton's third law within the multipole error.
@@ -37,17 +37,17 @@ G_CONST = 6.67e-11
 # body is known to ~1e-4 and the MEDIAN error is set by that, not by summation rounding.
 # measured (profiles/r04_final/parity_classes.txt): C4, all 4,194,304 bodies: 9.3e-7 / 1.3e-4 / 2.3e-2 (round 3, 65,536 sampled
 # bodies: 5.1e-7 / 8.8e-5 / 7.3e-4 -- the maximum is one body's value, and 64x more bodies contain worse cancellations; every clean
-# body stays inside the forward rounding model, max err / model 0.65); C5, 1,048,576 bodies: 2.8e-6 / 3.6e-4 / 1.24e-2 (1.8e-6 /
-# 3.8e-4 / 7.0e-3 on 65,536)
+# body stays inside the forward rounding model, max err / model 0.65); C5, all 16,777,216 bodies: 5.9e-6 / 4.9e-4 / 3.5e-2, max
+# err / model 0.59 (a sample of 1,048,576 from core, halo and in between: 2.8e-6 / 3.6e-4 / 1.24e-2; 65,536: 1.8e-6 / 3.8e-4 / 7.0e-3)
 TOL_C4 = (1.9e-6, 2.6e-4, 4.7e-2)
-TOL_C5 = (5.6e-6, 7.3e-4, 2.5e-2)
+TOL_C5 = (1.2e-5, 9.8e-4, 7.1e-2)
 # theta 0.3 at N = 65,536, measured (seed 1): fp32 2.7e-7 / 2.2e-5 / 1.7e-4 (uniform), 1.8e-7 / 1.0e-5 / 6.3e-5 (Plummer);
 # mixed, worst of SIX seeds (1-5 and this test's 7; round 4, profiles/r04_final/parity_classes.txt): uniform 8.2e-7 / 6.1e-5 /
 # 8.3e-4 (seed by seed the maximum -- one body's value -- is 3.4e-4, 4.0e-4, 7.3e-4, 8.3e-4, 4.7e-4, 4.3e-4), Plummer 4.4e-7 /
 # 3.2e-5 / 3.2e-4.  Tolerance = 2x the worst.
 TOL_65K = {G.Precision.F32: (5.4e-7, 4.4e-5, 3.4e-4), G.Precision.MIXED: (1.7e-6, 1.3e-4, 1.7e-3)}
 SAMPLE_C4 = 0            # all bodies
-SAMPLE_C5 = 1 << 20
+SAMPLE_C5 = 0            # all bodies
 
 
 def rel(a, ref):
@@ -86,7 +86,7 @@ def single_context_checks(n, theta, precision, m, p, v, s, tol):
     rep = PC.classify(a1, cnt, m, p, theta, s, pos_rounded=(precision == G.Precision.MIXED))
     # (theta 0.3 in mixed precision: a body evaluates ~1,300 criteria against ~450 at theta 0.5, each with the
     # rounding of both ends' positions in it: 0.8 % of the bodies have a borderline cell, 0.15 % at theta 0.5)
-    PC.check(rep, tol, min_clean=0.985 if precision == G.Precision.MIXED else 0.995)
+    PC.check(rep, tol, min_clean=0.98 if precision == G.Precision.MIXED else 0.995)      # (C5, all bodies: 98.53 % clean)
     n21 = len(O.build_tree(p, m, 21))
     assert st.n_nodes == 1 + 4 * st.n_internal == n21                            # the depth-21 oracle tree
     net = np.abs((m[:, None] * a1).sum(0)).max()                                 # Newton's third law
@@ -135,7 +135,7 @@ def test_config5_sixteen_million_bodies_theta_03_mixed_precision():
     m, p, v = IC.make("plummer", n, 1, quasi_static=True)
     # fp64 positions that are NOT fp32-representable (the point of the configuration)
     p = p * (1.0 + 3e-9 * np.random.default_rng(1).standard_normal(p.shape))
-    m, p, v, s = PC.sample_first(m, p, v, SAMPLE_C5)
+    m, p, v, s = PC.sample_first(m, p, v, SAMPLE_C5 or n)
     a1 = single_context_checks(n, 0.3, G.Precision.MIXED, m, p, v, s, TOL_C5)
     sample = np.random.default_rng(5).choice(n, 96, replace=False)
     emulated_ranks_checks(8, 0.3, G.Precision.MIXED, m, p, v, a1, sample, let_cap=32768)
