@@ -688,6 +688,12 @@ def main():
             leg["step_roofline"] = step_roofline(leg["ms_per_step"], n, leg["roofline"]["u64_nodes_per_body"],
                                                  leg["build_bytes_per_body"], kind="f64")
             out["secondary_f64"] = {"workload": f"{a.init}_N{n}_theta{a.theta}_depth{a.max_depth}_fast_fp64", **leg}
+            # ... and at BASELINE config 1's size and cap (N = 1,024, cap 10), next to secondary_exact.C1: one wave's chain
+            m1, p1, v1 = IC.make("uniform", 1024, a.seed, quasi_static=True)
+            cfg_1 = G.BhConfig(capacity=1024, theta=a.theta, max_depth=10, precision=G.Precision.F64, reference_compat=True,
+                               device=local)
+            leg, _, _ = timed_leg(G, cfg_1, m1, p1, v1, 200, 2, want_state=False)
+            out["secondary_f64_c1"] = {"workload": f"uniform_N1024_theta{a.theta}_depth10_fast_fp64", "steps": 200, **leg}
         if world == 1 and not a.no_secondary and a.other_configs:
             out["other_configs"] = other_configs(G, IC, local, a.seed, FLAG_WALK_STATS,
                                                  [t for t in a.other_configs.split(",") if t])
