@@ -60,6 +60,7 @@ struct bh_ctx {
     int64_t internal_cap = 0, node_cap = 0;
     int sort_passes = 0;
     bool state64 = false;          // fp64 state arrays: exact and mixed precision
+    int exact_bpw = 0;             // BH_EXACT_BPW: bodies per wavefront in the fp64 walks (0 = by launch size; 64 = rounds 1-3)
     int walk_split = 0;            // 0 = automatic
     bool walk_asm = true;          // BH_WALK_ASM=0: the C++ loop everywhere (A/B)
     int sort_bucket = 1;           // 1: bucket sort when the previous build's sorted positions are this body set's
@@ -465,6 +466,28 @@ int enqueue_build(bh_ctx *c)
     }
 }
 
+// fp64 walks (exact and throughput): bodies per wavefront for a launch of `cnt` bodies.  A wave's walk is one dependent chain
+// over the union of its bodies' walks (~900 node visits for 64 bodies, ~150 for one), and up to ~130k bodies the launch cannot
+// fill the GPU's 8,192 wave slots with 64-body waves anyway.  Measured (scripts/bpw_ab.py, profiles/r04_f64/bpw_sweep.txt): the
+// best number of waves is ~2,048 for the bit-exact walk (107 vector instructions per visit: more waves soon cost more vector
+// work than the shorter chains return) and ~4,096 for the throughput walk; the smallest power of two that stays below that, and
+// within what `partial` holds (one record per workgroup).  The bit-exact mode's results do not depend on it, bit for bit.
+static int exact_bodies_per_wave(const bh_ctx *c, int64_t cnt)
+{
+    // (the throughput walk adds a lane's terms in the order its WAVE meets them: its last bits depend on who shares the wave, like
+    // the fp32 split walk's -- BH_FLAG_WALK_NO_SPLIT pins 64 bodies per wave for callers that need launch-size independence)
+    if (c->fast64 && (c->cfg.flags & BH_FLAG_WALK_NO_SPLIT)) return kWave;
+    int b = 1;
+    if (c->exact_bpw > 0) b = c->exact_bpw;
+    else {
+        const int64_t waves = c->fast64 ? 4096 : 2048;
+        while (b < kWave && (int64_t)b * waves < cnt) b <<= 1;
+    }
+    const int64_t room = std::max<int64_t>(1024, (c->cfg.capacity + kWave - 1) / kWave);      // records in `partial`
+    while (b < kWave && (cnt + (int64_t)kWavesPerBlock * b - 1) / ((int64_t)kWavesPerBlock * b) > room) b <<= 1;
+    return b;
+}
+
 int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
 {
     int64_t lo, hi;
@@ -505,16 +528,18 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
         const bool use_asm = c->walk_asm && !stats && !(c->cfg.flags & BH_FLAG_WALK_PORTABLE) &&
                              c->node_cap * (int64_t)sizeof(NodeD) < (1ll << 32);
         const bool deep = 3 * c->Dm + 1 > kWave;                 // (deeper than 21 levels: the two-tier stack)
+        const int bpw = exact_bodies_per_wave(c, std::min(pass, hi - lo));
+        const int per_block = (kF64Block / kWave) * bpw;         // bodies per workgroup
         for (int64_t plo = lo; plo < hi; plo += pass) {
             const int64_t phi = std::min(hi, plo + pass);
-            double *pp = partial ? partial + 4 * ((plo - lo) / kF64Block) : nullptr;
+            double *pp = partial ? partial + 4 * ((plo - lo) / per_block) : nullptr;
             WalkF64Args wa{};
             wa.gd = c->gd; wa.ld = c->ld; wa.perm = c->perm; wa.pos = (double2 *)c->pos; wa.vel = (double2 *)c->vel;
             wa.mass = (const double *)c->mass; wa.force_out = (double2 *)c->force; wa.lo = plo; wa.hi = phi;
             wa.G = c->cfg.G; wa.dt = c->cfg.dt; wa.integrate = integrate ? 1 : 0; wa.ctr = c->ctr; wa.partial = pp;
-            wa.body_counts = stats ? c->body_counts : nullptr; wa.slots = slots;
+            wa.body_counts = stats ? c->body_counts : nullptr; wa.slots = slots; wa.bpw = bpw;
             auto args = [&](auto kern) {
-                hipLaunchKernelGGL(kern, dim3(blocks_for(phi - plo, kF64Block)), dim3(kF64Block), 0, c->stream, wa);
+                hipLaunchKernelGGL(kern, dim3(blocks_for(phi - plo, per_block)), dim3(kF64Block), 0, c->stream, wa);
                 c->walk_launches += 1;
             };
             auto pick = [&](auto compat_tag, auto deep_tag) {
@@ -527,22 +552,25 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
             if (c->compat) { if (deep) pick(T{}, T{}); else pick(T{}, Fz{}); }
             else           { if (deep) pick(Fz{}, T{}); else pick(Fz{}, Fz{}); }
         }
-        per_partial = kF64Block;
+        per_partial = per_block;
         BH_HIP(c, hipGetLastError());
     } else if (c->exact) {
+        const int bpw = exact_bodies_per_wave(c, std::min(pass, hi - lo));
+        const int per_block = kWavesPerBlock * bpw;              // bodies per workgroup
         for (int64_t plo = lo; plo < hi; plo += pass) {
             const int64_t phi = std::min(hi, plo + pass);
-            double *pp = partial ? partial + 4 * ((plo - lo) / kBlock) : nullptr;
+            double *pp = partial ? partial + 4 * ((plo - lo) / per_block) : nullptr;
             auto args = [&](auto kern) {
-                hipLaunchKernelGGL(kern, dim3(blocks_for(phi - plo, kBlock)), dim3(kBlock), 0, c->stream, c->gd, c->ld, c->perm,
+                hipLaunchKernelGGL(kern, dim3(blocks_for(phi - plo, per_block)), dim3(kBlock), 0, c->stream, c->gd, c->ld, c->perm,
                                    (double2 *)c->pos, (double2 *)c->vel, (const double *)c->mass,
                                    (double2 *)c->force, plo, phi, c->cfg.theta, c->cfg.G, c->cfg.dt,
-                                   integrate ? 1 : 0, c->ctr, pp, slots);
+                                   integrate ? 1 : 0, c->ctr, pp, slots, bpw);
                 c->walk_launches += 1;
             };
             if (c->compat) { if (stats) args(walk_exact_kernel<true, true>); else args(walk_exact_kernel<true, false>); }
             else           { if (stats) args(walk_exact_kernel<false, true>); else args(walk_exact_kernel<false, false>); }
         }
+        per_partial = per_block;
         BH_HIP(c, hipGetLastError());
     } else {
         WalkFastArgs a{};
@@ -662,6 +690,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     c->device = cfg->device;
     c->sort_passes = (2 * c->Dm + kRadixBits - 1) / kRadixBits;
     if (const char *e = std::getenv("BH_WALK_SPLIT")) c->walk_split = std::atoi(e);
+    if (const char *e = std::getenv("BH_EXACT_BPW")) { const int b = std::atoi(e); c->exact_bpw = (b >= 1 && b <= kWave && (b & (b - 1)) == 0) ? b : 0; }
     if (const char *e = std::getenv("BH_WALK_ASM")) c->walk_asm = std::atoi(e) != 0;
     if (const char *e = std::getenv("BH_SORT_PACK")) c->sort_pack = std::atoi(e) != 0;
     if (const char *e = std::getenv("BH_SORT_BUCKET")) c->sort_bucket = std::atoi(e);

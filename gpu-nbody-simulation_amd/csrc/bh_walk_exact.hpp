@@ -25,8 +25,12 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
     const NodeD *__restrict__ gd, const LinkD *__restrict__ ld, const uint32_t *__restrict__ perm,
     double2 *__restrict__ pos, double2 *__restrict__ vel, const double *__restrict__ mass,
     double2 *__restrict__ force_out, int64_t lo, int64_t hi, double theta, double G, double dt,
-    int integrate, TreeCounters *ctr, double *__restrict__ partial, double *slots)
+    int integrate, TreeCounters *ctr, double *__restrict__ partial, double *slots, int bpw)
 {
+    // bpw: bodies per wavefront, a power of two <= 64 (lanes bpw .. 63 idle).  A wave's walk is ONE dependent chain over the
+    // union of its lanes' walks; a launch of few bodies leaves the GPU empty however it is cut, so the engine gives every
+    // wave fewer bodies -- 1 at N <= 4,096 -- and the chain shrinks to one body's walk (config 1, N = 1,024: 0.30 -> see
+    // DESIGN.md section 4).  Every lane still adds its own terms in the reference's order: same bits.
     // The traversal stack -- one entry per tree level: {quad of the level, next child to visit, lanes that walk it} -- lives
     // in four VGPRs, entry k in lane k (round 3; it was three LDS arrays written by lane 0 and read back through
     // v_readfirstlane: a round trip through LDS on every visited node of a walk that is one long dependent chain).
@@ -34,8 +38,8 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
 
     if (ctr->overflow) return;
     const int lane = lane_id();
-    const int64_t s = lo + (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = s < hi;
+    const int64_t s = lo + ((int64_t)blockIdx.x * kWavesPerBlock + wave_id()) * bpw + lane;
+    const bool valid = lane < bpw && s < hi;
     const int64_t body = valid ? (int64_t)perm[s] : -1;
     const double2 p = valid ? pos[body] : double2{0.0, 0.0};
     const double mi = valid ? mass[body] : 0.0;

@@ -281,6 +281,7 @@ struct WalkF64Args {
     double *partial;               // per-workgroup min/max of the new positions (next root box), may be null
     uint32_t *body_counts;         // counting variant: accepted force evaluations per body, may be null
     double *slots;                 // bh_bounds.hpp: running bounds records, may be null
+    int32_t bpw, pad1;             // bodies per wavefront, a power of two <= 64 (see walk_exact_kernel): few bodies, short chains
 };
 
 template <bool COMPAT, bool STATS, bool DEEP = false, bool ASM = false>
@@ -294,8 +295,8 @@ __global__ __launch_bounds__(kF64Block) void walk_f64_kernel(WalkF64Args a)
 #endif
     if (a.ctr->overflow) return;
     const int lane = lane_id();
-    const int64_t s = a.lo + (int64_t)blockIdx.x * kF64Block + threadIdx.x;
-    const bool valid = s < a.hi;
+    const int64_t s = a.lo + ((int64_t)blockIdx.x * (kF64Block / kWave) + wave_id()) * a.bpw + lane;
+    const bool valid = lane < a.bpw && s < a.hi;
     const int64_t body = valid ? (int64_t)a.perm[s] : -1;
     const double2 p = valid ? a.pos[body] : double2{0.0, 0.0};
     const double mi = valid ? a.mass[body] : 0.0;

@@ -75,7 +75,11 @@ typedef enum bh_precision {
                                            per-body criterion, but another order of the fp32
                                            sums, so a body's last bits then depend on how many
                                            bodies its launch walks (still reproducible run to
-                                           run).  Set this to rule that out.                 */
+                                           run).  Set this to rule that out.  BH_PRECISION_F64 likewise:
+                                           launches of few bodies give a wavefront fewer than 64 of them
+                                           (shorter walks), which changes the order of a body's fp64 sum;
+                                           the flag pins 64.  (The bit-exact mode does the same and needs no
+                                           flag: its order is the reference's whoever shares the wave.)   */
 
 #define BH_FLAG_WALK_PORTABLE (1u << 3) /* fp32 and BH_PRECISION_F64 walks: the C++ traversal loop instead of the
                                            hand-scheduled gfx950 assembly loop.  Same operations

@@ -272,3 +272,44 @@ def test_any_theta_matches_the_oracle_bitwise(theta, compat):
         _, vel, pos = O.integrate(O.compute_forces(tt, pos, m, theta=theta, G=Gc, compat_self_skip=compat), m, vel, pos, dt=dt)
     # (a body inside a multi-occupant cap cell can sit exactly on the aggregate: inf * 0 = NaN on both sides)
     assert np.array_equal(pp, pos, equal_nan=True) and np.array_equal(vv, vel, equal_nan=True)
+
+
+@pytest.mark.parametrize("precision", [G.Precision.F64_EXACT, G.Precision.F64])
+@pytest.mark.parametrize("n", [1000, 5000, 40960])
+def test_bodies_per_wavefront(gold, precision, n):
+    """Round 4: launches of few bodies give every wavefront of the fp64 walks fewer than 64 bodies (1 at N <= 2,048 / 4,096) so that
+    its walk -- one dependent chain over the union of its bodies' walks -- is short (config 1: 0.30 -> 0.10 ms).  In the BIT-EXACT
+    mode every lane adds its own terms in the reference's order whoever shares its wave: forces, counters and a 3-step trajectory
+    are bitwise the same for 1, 4, 16 and 64 bodies per wave and for the engine's own choice -- and the reference's.  The
+    THROUGHPUT mode adds a lane's terms in the order its wave meets them: same counters, forces within 1e-13 of each other, and
+    bitwise equal again under BH_FLAG_WALK_NO_SPLIT, which pins 64 bodies per wave."""
+    from gpu_nbody_simulation_amd.engine import FLAG_WALK_NO_SPLIT
+    g = gold("ref_project_40960")
+    m, p, v = g["mass"][:n], g["pos"][:n], g["vel"][:n]
+    exact = precision == G.Precision.F64_EXACT
+    out, pinned = [], []
+    try:
+        for bpw in ("0", "1", "4", "16", "64"):
+            os.environ["BH_EXACT_BPW"] = bpw
+            for flags, dst in ((FLAG_WALK_STATS, out), (FLAG_WALK_STATS | FLAG_WALK_NO_SPLIT, pinned)):
+                with G.BarnesHutEngine(G.BhConfig(capacity=n, precision=precision, flags=flags)) as e:
+                    e.upload(p, v, m)
+                    f = e.compute_forces()
+                    st = e.stats()
+                    e.step(3)
+                    dst.append((f, (st.visits, st.interactions)) + e.download())
+    finally:
+        os.environ.pop("BH_EXACT_BPW", None)
+    same = lambda a, b: all(np.array_equal(x, y, equal_nan=True) for x, y in ((a[0], b[0]), (a[2], b[2]), (a[3], b[3]))) and a[1] == b[1]
+    for o in out[1:]:
+        if exact:
+            assert same(o, out[0])
+        else:
+            ok = np.isfinite(out[0][0]).all(axis=1)
+            r = np.linalg.norm(o[0][ok] - out[0][0][ok], axis=1) / np.linalg.norm(out[0][0][ok], axis=1)
+            assert o[1] == out[0][1] and r.max() <= 1e-13
+    if not exact:
+        for o in pinned[1:]:
+            assert same(o, pinned[0])
+    if exact and n == 40960:
+        assert np.array_equal(out[0][0], g["forces_0"])                              # (and they are the reference's)
