@@ -165,3 +165,29 @@ def test_bench_let_path_with_three_ranks_sharing_the_gpu(tmp_path):
             # (a cell that straddles two ranks becomes two partial cells, each accepted on its own: the forest does a
     # little MORE work per body than one tree -- +10 % at this small size on 3 ranks -- never less)
     assert 1.0 <= d["interactions_per_body"] / one_let["interactions_per_body"] <= 1.15
+
+
+def test_bench_starts_its_own_ranks_when_nobody_launched_it(tmp_path):
+    """`python bench.py --gpus 2` with no RANK in the environment must not fall back to one rank: it starts
+    its own two ranks through torch.distributed.run (bench.spawn_ranks) and the line they print says so.
+    Both ranks share this one GPU here, so the collectives go over gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", BHGPU_REHEARSE_ON_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                        "--steps", "3", "--warmup", "1", "--n-bodies", "65536", "--no-cpu-baseline", "--no-secondary"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl"] == {"world_size": 2, "backend": "gloo"}
+    assert d["config"]["parallelism"].startswith("orb x2")
+    assert d["let"]["direct_sum_check"]["worst_rank_median_rel_err"] < 3e-2
+    lo, hi = d["let"]["efficiency_inputs"]["bodies_per_rank_min"], d["let"]["efficiency_inputs"]["bodies_per_rank_max"]
+    assert lo + hi == 65536 and hi - lo < 0.05 * 65536
