@@ -51,6 +51,7 @@ struct bh_ctx {
     bh_config cfg{};
     int Dm = 0;
     bool exact = true, compat = true;
+    bool exact_thr = false;        // BH_PRECISION_F64_EXACT: nodes carry exact d2 thresholds for the walk's acceptance test (off: BH_FLAG_WALK_PORTABLE)
     bool fast64 = false;           // BH_PRECISION_F64: the exact mode's tree and state, the throughput walk of bh_walk_f64.hpp
     int device = 0;
     hipStream_t stream = nullptr;
@@ -422,7 +423,8 @@ int enqueue_build_t(bh_ctx *c)
         const int64_t span = std::max<int64_t>(1, std::min<int64_t>(c->internal_cap, std::max<int64_t>(n - 1, 0) * (int64_t)std::max(1, Dm)));
         hipLaunchKernelGGL(nodes_exact_kernel, dim3(blocks_for(span, kBlock)), dim3(kBlock), 0, st, c->keys_sorted, c->perm,
                            c->cnt, c->cell_first, pos, mass, c->box, n, Dm, c->internal_cap, c->gd, c->ld, c->self_node,
-                           c->cell_depth, c->com_pending, c->ctr, c->fast64 ? c->cfg.theta : 0.0);
+                           c->cell_depth, c->com_pending, c->ctr, (c->fast64 || c->exact_thr) ? c->cfg.theta : 0.0,
+                           c->exact_thr ? 1 : 0);
     } else {
         launch_nodes_fast(c, false, st);
     }
@@ -567,8 +569,13 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
                                    integrate ? 1 : 0, c->ctr, pp, slots, bpw);
                 c->walk_launches += 1;
             };
-            if (c->compat) { if (stats) args(walk_exact_kernel<true, true>); else args(walk_exact_kernel<true, false>); }
-            else           { if (stats) args(walk_exact_kernel<false, true>); else args(walk_exact_kernel<false, false>); }
+            auto pick = [&](auto thr_tag) {
+                constexpr bool TH = decltype(thr_tag)::value;
+                if (c->compat) { if (stats) args(walk_exact_kernel<true, true, TH, false>); else args(walk_exact_kernel<true, false, TH, TH>); }
+                else           { if (stats) args(walk_exact_kernel<false, true, TH, false>); else args(walk_exact_kernel<false, false, TH, TH>); }
+            };
+            // (the node kernel stored what this walk reads in the size slot: exact thresholds, or the sizes for the portable walk)
+            if (c->exact_thr) pick(std::true_type{}); else pick(std::false_type{});
         }
         per_partial = per_block;
         BH_HIP(c, hipGetLastError());
@@ -692,6 +699,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     if (const char *e = std::getenv("BH_WALK_SPLIT")) c->walk_split = std::atoi(e);
     if (const char *e = std::getenv("BH_EXACT_BPW")) { const int b = std::atoi(e); c->exact_bpw = (b >= 1 && b <= kWave && (b & (b - 1)) == 0) ? b : 0; }
     if (const char *e = std::getenv("BH_WALK_ASM")) c->walk_asm = std::atoi(e) != 0;
+    c->exact_thr = c->exact && !c->fast64 && c->walk_asm && !(cfg->flags & BH_FLAG_WALK_PORTABLE);
     if (const char *e = std::getenv("BH_SORT_PACK")) c->sort_pack = std::atoi(e) != 0;
     if (const char *e = std::getenv("BH_SORT_BUCKET")) c->sort_bucket = std::atoi(e);
     if (const char *e = std::getenv("BH_BUILD_ITEMS")) c->build_items = std::atoi(e);

@@ -628,6 +628,46 @@ __device__ __forceinline__ double f64_walk_threshold(double size, double theta)
     return (double)INFINITY;
 }
 
+// BH_PRECISION_F64_EXACT (bh_walk_exact.hpp) -- the SAME criterion solved for d2 EXACTLY: the smallest double T with
+//     size / (sqrt(T) + 1e-15) < theta        (every operation correctly rounded, as the reference computes it)
+// sqrt, + and / are monotone under rounding, so the lanes that accept a node are exactly those with d2 >= T: the walk
+// decides with one comparison what the reference decides with a square root and a division, bit for bit the same
+// decisions.  NaN when no distance accepts (theta or size not finite; d2 >= NaN never holds -- and a NaN d2 fails
+// against every T, as NaN < theta fails in the reference).  Found by galloping from the real-valued solution over
+// the doubles' bit patterns (ordered as integers for non-negative values) and bisecting: a handful of evaluations.
+__device__ __forceinline__ double exact_walk_threshold(double size, double theta)
+{
+    auto acc = [&](uint64_t bits) { return size / (sqrt(__longlong_as_double((long long)bits)) + 1e-15) < theta; };
+    constexpr uint64_t kInf = 0x7ff0000000000000ull;
+    if (!acc(kInf)) return __longlong_as_double(0x7ff8000000000000ll);
+    if (acc(0ull)) return 0.0;
+    uint64_t lo = 0ull, hi = kInf;                               // acc(lo) false, acc(hi) true
+    const double s = size / theta - 1e-15;
+    double t0 = (s > 0.0) ? s * s : 0.0;
+    uint64_t g = (t0 < (double)INFINITY) ? (uint64_t)__double_as_longlong(t0) : kInf - 1;
+    if (g < 1ull) g = 1ull;
+    if (acc(g)) {
+        hi = g;
+        for (uint64_t step = 1;; step <<= 1) {
+            if (hi - lo <= step) break;
+            const uint64_t c = hi - step;
+            if (acc(c)) hi = c; else { lo = c; break; }
+        }
+    } else {
+        lo = g;
+        for (uint64_t step = 1;; step <<= 1) {
+            if (hi - lo <= step) break;
+            const uint64_t c = lo + step;
+            if (acc(c)) { hi = c; break; } else lo = c;
+        }
+    }
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (acc(mid)) hi = mid; else lo = mid;
+    }
+    return __longlong_as_double((long long)hi);
+}
+
 // ---- exact-mode nodes kernel: one thread per subdivided cell writes its four children ---------------
 // NodeD/LinkD + self_node / pending (subdivided children per cell) for the bottom-up pass.  Round 1 ran one
 // thread per sorted neighbour pair, and the pair that starts a chain of nested cells handled them in turn:
@@ -643,10 +683,18 @@ __global__ __launch_bounds__(kBlock) void nodes_exact_kernel(
     const double2 *__restrict__ pos, const double *__restrict__ mass,
     const double *__restrict__ box, int64_t n, int Dm, int64_t internal_cap, NodeD *__restrict__ gd,
     LinkD *__restrict__ ld, int32_t *__restrict__ self_node, int32_t *__restrict__ cell_depth,
-    uint32_t *__restrict__ pending, TreeCounters *ctr, double walk_theta)
+    uint32_t *__restrict__ pending, TreeCounters *ctr, double walk_theta, int exact_thr)
 {
-    // walk_theta > 0 (BH_PRECISION_F64): the `size` slot of every node carries the walk's d2 threshold instead
-    auto size_slot = [&](double size) { return walk_theta > 0.0 ? f64_walk_threshold(size, walk_theta) : size; };
+    // walk_theta > 0: the `size` slot of every node carries the walk's d2 threshold instead -- BH_PRECISION_F64's
+    // (f64_walk_threshold) or, with exact_thr, the exact one of the bit-exact walk (the four children of a cell are
+    // almost always the same size: one search per cell)
+    double memo_size = -1.0, memo_thr = 0.0;
+    auto size_slot = [&](double size) {
+        if (!(walk_theta > 0.0)) return size;
+        if (!exact_thr) return f64_walk_threshold(size, walk_theta);
+        if (!(size == memo_size)) { memo_size = size; memo_thr = exact_walk_threshold(size, walk_theta); }
+        return memo_thr;
+    };
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint32_t total = ctr->n_internal;
 

@@ -313,3 +313,84 @@ def test_bodies_per_wavefront(gold, precision, n):
             assert same(o, pinned[0])
     if exact and n == 40960:
         assert np.array_equal(out[0][0], g["forces_0"])                              # (and they are the reference's)
+
+
+def _threshold_cases():
+    rng = np.random.default_rng(11)
+
+    def clumped(n):
+        p = np.concatenate([rng.normal(0, 1e-3, (n // 2, 2)), rng.uniform(-1, 1, (n - n // 2, 2))])
+        m, v = rng.uniform(0.1, 0.5, n), rng.uniform(-1e-9, 1e-9, (n, 2))
+        m[::7] = 1e-16                                            # below the reference's 1e-15 cut-off
+        return m, p, v
+
+    def lattice(n):                                               # dx = 0 / dy = 0 exactly between many pairs
+        k = int(np.sqrt(n))
+        g = np.stack(np.meshgrid(np.arange(k), np.arange(k)), -1).reshape(-1, 2).astype(np.float64) / 64.0
+        return np.full(len(g), 0.25), g, np.zeros_like(g)
+
+    cases = {}
+    m, p, v = clumped(30000); cases["clumped"] = (m, p, v, dict(max_depth=8))
+    m, p, v = clumped(30000); cases["clumped_deep"] = (m, p, v, dict(max_depth=32, reference_compat=False))
+    m, p, v = lattice(16384); cases["lattice"] = (m, p, v, dict(max_depth=12))
+    # operand ranges where IEEE division / sqrt need their range handling: the walk must leave its short sequences
+    m, p, v = clumped(20000); cases["huge_coordinates"] = (m, p * 1e130, v, dict(max_depth=21))      # d2 ~ 1e260 > 2^400
+    m, p, v = clumped(20000); cases["tiny_coordinates"] = (m, p * 1e-140, v, dict(max_depth=21))     # d2 ~ 1e-280 < 2^-400
+    m, p, v = clumped(20000); cases["tiny_G"] = (m, p, v, dict(max_depth=21, G=1e-130))              # G m_i < 2^-150
+    m, p, v = clumped(20000); cases["huge_masses"] = (m * 1e80, p, v * 0, dict(max_depth=21, dt=1e-200))   # node masses > 2^150
+    m, p, v = clumped(20000); p[5] = (1e200, -1e200); p[77] = (3e-300, 1.0)                          # d2 = inf from one body; a denormal-ish dx
+    cases["one_body_at_1e200"] = (m, p, v, dict(max_depth=21))
+    m, p, v = clumped(20000); m[::3] *= 1e-10; m[1::3] *= 1e60                                        # lanes of one wave on both sides of the range test
+    cases["mixed_mass_ranges"] = (m, p, v, dict(max_depth=21))
+    for th in (1e-9, 0.01, 1.7, 40.0):
+        m, p, v = clumped(8000); cases[f"theta_{th}"] = (m, p, v, dict(max_depth=14, theta=th))
+    return cases
+
+
+_THR_CASES = _threshold_cases()
+
+
+@pytest.mark.parametrize("name", sorted(_THR_CASES))
+def test_threshold_walk_equals_the_walk_written_as_the_reference_writes_it(name):
+    """Round 4: the bit-exact walk decides acceptance by comparing d2 with the node's EXACT threshold (the smallest double
+    whose sqrt, + 1e-15 and division give size / d < theta: exact_walk_threshold, csrc/bh_tree.hpp) and runs sqrt and the
+    three divisions of an accepted term through the compiler's own instruction sequences without their range handling
+    whenever every taking lane's operands are inside the range where that handling is the identity
+    (csrc/bh_walk_exact.hpp).  BH_FLAG_WALK_PORTABLE runs the walk as the reference writes it -- sqrt, size / d < theta,
+    three divisions -- on a tree whose nodes carry their sizes.  Forces, counters and the state after 3 steps are BITWISE
+    equal on ordinary inputs and on inputs that leave every range (d2 = inf and 1e-280, G m = 1e-150, exact zeros in dx)."""
+    from gpu_nbody_simulation_amd.engine import FLAG_WALK_PORTABLE
+    m, p, v, kw = _THR_CASES[name]
+    n = len(m)
+    res = []
+    for flags in (FLAG_WALK_STATS, FLAG_WALK_STATS | FLAG_WALK_PORTABLE, 0):
+        with G.BarnesHutEngine(G.BhConfig(capacity=n, flags=flags, **kw)) as e:
+            e.upload(p, v, m)
+            f = e.compute_forces()
+            st = e.stats()
+            e.step(3)
+            res.append((f, (st.visits, st.interactions) if flags else None) + e.download())
+    assert res[0][1] == res[1][1] and res[0][1][1] > 0
+    for other in res[1:]:
+        for x, y in zip(res[0], other):
+            if x is not None and y is not None and not isinstance(x, tuple):
+                assert np.array_equal(x, y, equal_nan=True)
+    assert np.isfinite(res[0][0]).mean() > 0.9                    # (not a comparison of NaNs)
+
+
+def test_threshold_walk_full_size():
+    """... and on all 1,048,576 bodies of config 3 (Plummer, theta 0.5, uncapped)."""
+    from gpu_nbody_simulation_amd.engine import FLAG_WALK_PORTABLE
+    from gpu_nbody_simulation_amd import initial_conditions as IC
+    n = 1 << 20
+    m, p, v = IC.make("plummer", n, 1, quasi_static=True)
+    res = []
+    for flags in (0, FLAG_WALK_PORTABLE):
+        with G.BarnesHutEngine(G.BhConfig(capacity=n, max_depth=21, flags=flags)) as e:
+            e.upload(p, v, m)
+            f = e.compute_forces()
+            e.step(2)
+            res.append((f,) + e.download())
+    assert np.isfinite(res[0][0]).all() and np.abs(res[0][0]).max() > 0
+    for x, y in zip(res[0], res[1]):
+        assert np.array_equal(x, y)
