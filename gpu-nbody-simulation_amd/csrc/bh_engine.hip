@@ -569,13 +569,17 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
                                    integrate ? 1 : 0, c->ctr, pp, slots, bpw);
                 c->walk_launches += 1;
             };
-            auto pick = [&](auto thr_tag) {
-                constexpr bool TH = decltype(thr_tag)::value;
-                if (c->compat) { if (stats) args(walk_exact_kernel<true, true, TH, false>); else args(walk_exact_kernel<true, false, TH, TH>); }
-                else           { if (stats) args(walk_exact_kernel<false, true, TH, false>); else args(walk_exact_kernel<false, false, TH, TH>); }
+            // (the node kernel stored what this walk reads in the size slot: exact thresholds, or the sizes for the portable
+            // walk; the hand-written loop uses 32-bit byte offsets into the node array and carries no counters)
+            const bool use_asm = c->exact_thr && !stats && c->node_cap * (int64_t)sizeof(NodeD) < (1ll << 32);
+            auto pick = [&](auto compat_tag) {
+                constexpr bool CP = decltype(compat_tag)::value;
+                if (!c->exact_thr) { if (stats) args(walk_exact_kernel<CP, true, false, false>); else args(walk_exact_kernel<CP, false, false, false>); }
+                else if (stats) args(walk_exact_kernel<CP, true, true, false>);
+                else if (use_asm) args(walk_exact_kernel<CP, false, true, true>);
+                else args(walk_exact_kernel<CP, false, true, false>);
             };
-            // (the node kernel stored what this walk reads in the size slot: exact thresholds, or the sizes for the portable walk)
-            if (c->exact_thr) pick(std::true_type{}); else pick(std::false_type{});
+            if (c->compat) pick(std::true_type{}); else pick(std::false_type{});
         }
         per_partial = per_block;
         BH_HIP(c, hipGetLastError());

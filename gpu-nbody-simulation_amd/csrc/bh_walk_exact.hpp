@@ -3,14 +3,18 @@
 // and updateAccVelPos (project.cu:819-836).  Compiled with -ffp-contract=off.
 //
 // One wavefront walks the tree for 64 Morton-adjacent bodies (one body per lane).  The traversal
-// state is wave-uniform and lives in LDS: one entry per tree level = {first child of the quad,
-// 64-bit mask of the lanes that opened the parent, next child to visit}.  Children are visited
+// state is wave-uniform: the level being walked = {first child of the quad, 64-bit mask of the
+// lanes that opened the parent, next child to visit} in scalar registers, the levels above it in
+// one lane each of four vector registers.  Children are visited
 // 3,2,1,0 -- the reference's pop order (it pushes 0..3 on a LIFO, project.cu:662-668) -- and a
 // child's whole subtree is finished before its sibling starts.  The wave therefore visits the
 // UNION of its lanes' private walks in the reference's DFS order, and each lane, masked to the
 // nodes its own walk would pop, adds its terms in exactly the reference's order: same fp64
 // operations, same order, same bits.  Node loads are wave-uniform (scalar loads), so a visit
-// costs one 40-byte read per wave instead of 64 divergent gathers.
+// costs 40 bytes per wave instead of 64 divergent gathers.
+// Three statements of the walk, bit-identical on every input (tests/test_gpu_exact.py): the hand-written gfx950 loop
+// (walk_exact_asm: the product), the C++ loop with the same arithmetic (the counting variant), and the walk written as the
+// reference writes it -- sqrt, size / d < theta, three divisions (BH_FLAG_WALK_PORTABLE).
 #pragma once
 
 #include "bh_tree.hpp"
@@ -20,6 +24,268 @@ namespace bh {
 constexpr int kExactLevels = 34;   // max_depth <= 32 -> at most 32 stacked levels
 extern "C" __device__ int exact_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 
+// ---- the traversal as one block of gfx950 assembly ---------------------------------------------------------------------
+// What the counters said of the C++ loop around a per-node block (profiles/r04_exact/): per visited node 47 vector
+// instructions, but also 55 scalar ones and 14 branches -- the scalar unit as busy as the vector pipe.  Here, per node:
+//   s_cmp + branch       empty node, from the high word of its mass (exact test out of line for the one word in between)
+//   v_add x2, v_mul x2   dx, dy, dx^2, dy^2          s_sub + s_cmp + branch: mass inside the range of the short sequences
+//   v_add                d2                           s_cmp + branch: leaf (occupant test by v_cmpx_ne_u32, out of line)
+//   v_cmpx_le_f64        thr <= d2: EXEC := the lanes that accept; s_andn2: the lanes that open
+//   s_cbranch_execz      nobody takes the node
+//   v_cmp x3, s_and x3   operand ranges of the takers (dx^2, dy^2 >= 2^-400, d2 <= 2^400, G m_i in 2^+-150); s_andn2 + branch
+//   36 x fp64            sqrt(d2) (v_rsq_f64, one coupled Newton step, two residual corrections), 1 / d2 and 1 / d
+//                        (v_rcp_f64 + two Newton steps each), three quotients q + r (a - b q), two products, two sums --
+//                        the instruction sequences the compiler expands sqrt() and `/` to, the three chains interleaved
+//   s_cmp_eq_u64 + branch  somebody opens: the level's state goes to lane m0 of four VGPRs (unless it is exhausted)
+// Children 3,2 and 1,0 of a quad are the halves of one 128-byte line: a pair is ONE s_load_dwordx16 (+ one x4 of links), and
+// the second child of a pair waits for nothing.  Out of line, bit for bit the compiler's full expansions (v_div_scale,
+// v_div_fmas, v_div_fixup; the 2^256 scaling and the class test of sqrt): any taker outside the ranges sends the wave
+// there for that node.  Fixed SGPRs: s[24:31] / s[32:39] the lower / upper node of the pair {cx, cy, m, thr}, s[40:43] their
+// links {child, occ}, s[44:49] scratch, s[64:65] the level's lanes, s66 its quad, s67 the next child, s[70:71] the lanes
+// that open; m0 = stack entries.  Fixed VGPRs: v[32:37] dx dy d2, v[38:51] scratch, v52..v55 the stack.
+// Hazards handled by hand (gfx940 family): an independent instruction or s_nop between a transcendental and its use; four
+// wait states between a vector write of EXEC and v_writelane; two between a vector write of VCC and v_cndmask; four
+// between v_div_scale's VCC and v_div_fmas; m0 written at least one instruction before a lane select uses it.
+#if defined(BH_ASM_GUARD) && BH_ASM_GUARD
+#define BHX_GUARD_INIT "s_mov_b32 s73, 0\n"
+#define BHX_GUARD "s_add_u32 s73, s73, 1\n s_cmp_gt_u32 s73, 0x400000\n s_cbranch_scc1 Ldone_%=\n"
+#define BHX_GUARD_CLOBBER "s73",
+#else
+#define BHX_GUARD_INIT ""
+#define BHX_GUARD ""
+#define BHX_GUARD_CLOBBER
+#endif
+#define BHX_DX "v[32:33]"
+#define BHX_DY "v[34:35]"
+#define BHX_D2 "v[36:37]"
+#define BHX_TA "v[38:39]"
+#define BHX_TB "v[40:41]"
+#define BHX_TC "v[42:43]"
+#define BHX_TD "v[44:45]"
+#define BHX_TE "v[46:47]"
+#define BHX_TF "v[48:49]"
+#define BHX_TG "v[50:51]"
+// the accepted term on checked operand ranges (M: the node's mass)
+#define BHX_FAST(M)                                                                                 \
+    "v_rsq_f64 " BHX_TA ", " BHX_D2 "\n"                                                            \
+    "v_rcp_f64 " BHX_TB ", " BHX_D2 "\n"                                                            \
+    "v_mul_f64 " BHX_TC ", %[gm], " M "\n"                          /* G m_i m                   */ \
+    "v_mul_f64 " BHX_TD ", " BHX_D2 ", " BHX_TA "\n"                /* g = d2 y                  */ \
+    "v_mul_f64 " BHX_TE ", " BHX_TA ", 0.5\n"                       /* h = y / 2                 */ \
+    "v_fma_f64 " BHX_TA ", -" BHX_D2 ", " BHX_TB ", 1.0\n"                                          \
+    "v_fma_f64 " BHX_TF ", -" BHX_TE ", " BHX_TD ", 0.5\n"          /* r = 1/2 - h g             */ \
+    "v_fma_f64 " BHX_TB ", " BHX_TB ", " BHX_TA ", " BHX_TB "\n"                                    \
+    "v_fma_f64 " BHX_TD ", " BHX_TD ", " BHX_TF ", " BHX_TD "\n"                                    \
+    "v_fma_f64 " BHX_TE ", " BHX_TE ", " BHX_TF ", " BHX_TE "\n"                                    \
+    "v_fma_f64 " BHX_TA ", -" BHX_D2 ", " BHX_TB ", 1.0\n"                                          \
+    "v_fma_f64 " BHX_TF ", -" BHX_TD ", " BHX_TD ", " BHX_D2 "\n"                                   \
+    "v_fma_f64 " BHX_TB ", " BHX_TB ", " BHX_TA ", " BHX_TB "\n"    /* 1 / d2                    */ \
+    "v_fma_f64 " BHX_TD ", " BHX_TF ", " BHX_TE ", " BHX_TD "\n"                                    \
+    "v_mul_f64 " BHX_TA ", " BHX_TC ", " BHX_TB "\n"                                                \
+    "v_fma_f64 " BHX_TF ", -" BHX_TD ", " BHX_TD ", " BHX_D2 "\n"                                   \
+    "v_fma_f64 " BHX_TG ", -" BHX_D2 ", " BHX_TA ", " BHX_TC "\n"                                   \
+    "v_fma_f64 " BHX_TD ", " BHX_TF ", " BHX_TE ", " BHX_TD "\n"    /* sqrt(d2)                  */ \
+    "v_fma_f64 " BHX_TA ", " BHX_TG ", " BHX_TB ", " BHX_TA "\n"    /* (G m_i m) / d2, :651      */ \
+    "v_add_f64 " BHX_TD ", " BHX_TD ", %[eps]\n"                    /* d = sqrt(d2) + 1e-15, :634 */ \
+    "v_rcp_f64 " BHX_TB ", " BHX_TD "\n"                                                            \
+    "s_nop 0\n"                                                                                     \
+    "v_fma_f64 " BHX_TC ", -" BHX_TD ", " BHX_TB ", 1.0\n"                                          \
+    "v_fma_f64 " BHX_TB ", " BHX_TB ", " BHX_TC ", " BHX_TB "\n"                                    \
+    "v_fma_f64 " BHX_TC ", -" BHX_TD ", " BHX_TB ", 1.0\n"                                          \
+    "v_fma_f64 " BHX_TB ", " BHX_TB ", " BHX_TC ", " BHX_TB "\n"    /* 1 / d                     */ \
+    "v_mul_f64 " BHX_TC ", " BHX_DX ", " BHX_TB "\n"                                                \
+    "v_mul_f64 " BHX_TE ", " BHX_DY ", " BHX_TB "\n"                                                \
+    "v_fma_f64 " BHX_TF ", -" BHX_TD ", " BHX_TC ", " BHX_DX "\n"                                   \
+    "v_fma_f64 " BHX_TG ", -" BHX_TD ", " BHX_TE ", " BHX_DY "\n"                                   \
+    "v_fma_f64 " BHX_TC ", " BHX_TF ", " BHX_TB ", " BHX_TC "\n"    /* dx / d, :654              */ \
+    "v_fma_f64 " BHX_TE ", " BHX_TG ", " BHX_TB ", " BHX_TE "\n"    /* dy / d, :655              */ \
+    "v_mul_f64 " BHX_TC ", " BHX_TA ", " BHX_TC "\n"                                                \
+    "v_mul_f64 " BHX_TE ", " BHX_TA ", " BHX_TE "\n"                                                \
+    "v_add_f64 %[fx], %[fx], " BHX_TC "\n"                                                          \
+    "v_add_f64 %[fy], %[fy], " BHX_TE "\n"
+// NUM / DEN -> RES, the compiler's expansion of an IEEE fp64 division (RES may be NUM); scratch: ta tb te tf tg
+#define BHX_DIV(RES, NUM, DEN)                                                                      \
+    "v_div_scale_f64 " BHX_TA ", s[48:49], " DEN ", " DEN ", " NUM "\n"                             \
+    "v_rcp_f64 " BHX_TB ", " BHX_TA "\n"                                                            \
+    "v_div_scale_f64 " BHX_TE ", vcc, " NUM ", " DEN ", " NUM "\n"                                  \
+    "v_fma_f64 " BHX_TF ", -" BHX_TA ", " BHX_TB ", 1.0\n"                                          \
+    "v_fma_f64 " BHX_TB ", " BHX_TB ", " BHX_TF ", " BHX_TB "\n"                                    \
+    "v_fma_f64 " BHX_TF ", -" BHX_TA ", " BHX_TB ", 1.0\n"                                          \
+    "v_fma_f64 " BHX_TB ", " BHX_TB ", " BHX_TF ", " BHX_TB "\n"                                    \
+    "v_mul_f64 " BHX_TF ", " BHX_TE ", " BHX_TB "\n"                                                \
+    "v_fma_f64 " BHX_TG ", -" BHX_TA ", " BHX_TF ", " BHX_TE "\n"                                   \
+    "s_nop 1\n"                                                                                     \
+    "v_div_fmas_f64 " BHX_TG ", " BHX_TG ", " BHX_TB ", " BHX_TF "\n"                               \
+    "v_div_fixup_f64 " RES ", " BHX_TG ", " DEN ", " NUM "\n"
+// the accepted term through the full expansions (EXEC = the lanes that take the node; dx dy d2 as left by BHX_EVAL)
+#define BHX_GENERIC(M)                                                                              \
+    "v_mul_f64 " BHX_TC ", %[gm], " M "\n"                                                          \
+    "s_mov_b32 s48, 0\n s_brev_b32 s49, 8\n"                        /* 2^-767 */                    \
+    "v_mov_b32 v50, 0x100\n"                                                                        \
+    "v_cmp_gt_f64 vcc, s[48:49], " BHX_D2 "\n"                      /* sqrt: tiny arguments scaled by 2^256 */ \
+    "v_mov_b32 v51, 0xffffff80\n"                                                                   \
+    "s_nop 1\n"                                                                                     \
+    "v_cndmask_b32 v50, 0, v50, vcc\n"                                                              \
+    "v_cndmask_b32 v51, 0, v51, vcc\n"                                                              \
+    "v_ldexp_f64 " BHX_TA ", " BHX_D2 ", v50\n"                                                     \
+    "v_rsq_f64 " BHX_TB ", " BHX_TA "\n"                                                            \
+    "v_mov_b32 v50, 0x260\n"                                        /* class: -0, +0, +inf */       \
+    "v_mul_f64 " BHX_TD ", " BHX_TA ", " BHX_TB "\n"                                                \
+    "v_mul_f64 " BHX_TB ", " BHX_TB ", 0.5\n"                                                       \
+    "v_fma_f64 " BHX_TE ", -" BHX_TB ", " BHX_TD ", 0.5\n"                                          \
+    "v_fma_f64 " BHX_TD ", " BHX_TD ", " BHX_TE ", " BHX_TD "\n"                                    \
+    "v_fma_f64 " BHX_TB ", " BHX_TB ", " BHX_TE ", " BHX_TB "\n"                                    \
+    "v_fma_f64 " BHX_TE ", -" BHX_TD ", " BHX_TD ", " BHX_TA "\n"                                   \
+    "v_fma_f64 " BHX_TD ", " BHX_TE ", " BHX_TB ", " BHX_TD "\n"                                    \
+    "v_fma_f64 " BHX_TE ", -" BHX_TD ", " BHX_TD ", " BHX_TA "\n"                                   \
+    "v_fma_f64 " BHX_TD ", " BHX_TE ", " BHX_TB ", " BHX_TD "\n"                                    \
+    "v_ldexp_f64 " BHX_TD ", " BHX_TD ", v51\n"                                                     \
+    "v_cmp_class_f64 vcc, " BHX_TA ", v50\n"                                                        \
+    "s_nop 1\n"                                                                                     \
+    "v_cndmask_b32 v44, v44, v38, vcc\n"                                                            \
+    "v_cndmask_b32 v45, v45, v39, vcc\n"                                                            \
+    "v_add_f64 " BHX_TD ", " BHX_TD ", %[eps]\n"                    /* d, project.cu:634 */         \
+    BHX_DIV(BHX_TC, BHX_TC, BHX_D2)                                 /* project.cu:651 */            \
+    BHX_DIV(BHX_DX, BHX_DX, BHX_TD)                                 /* project.cu:654 */            \
+    BHX_DIV(BHX_DY, BHX_DY, BHX_TD)                                 /* project.cu:655 */            \
+    "v_mul_f64 " BHX_TA ", " BHX_TC ", " BHX_DX "\n"                                                \
+    "v_mul_f64 " BHX_TB ", " BHX_TC ", " BHX_DY "\n"                                                \
+    "v_add_f64 %[fx], %[fx], " BHX_TA "\n"                                                          \
+    "v_add_f64 %[fy], %[fy], " BHX_TB "\n"
+// one node: EXEC = the level's lanes on entry; s[70:71] = the lanes that open it on exit (EXEC is left narrowed)
+#define BHX_EVAL(CX, CY, M, MLO, MHI, THR, CS, OS, T, COMPAT_CMP)                                   \
+    "s_mov_b64 s[70:71], 0\n"                                                                       \
+    "s_cmp_lt_u32 " MHI ", 0x3cd203af\n"                            /* m < 1e-15 for sure: empty, project.cu:617 */ \
+    "s_cbranch_scc1 Lend" T "_%=\n"                                                                 \
+    "v_add_f64 " BHX_DX ", " CX ", -%[px]\n"                                                        \
+    "v_add_f64 " BHX_DY ", " CY ", -%[py]\n"                                                        \
+    "s_sub_u32 s46, " MHI ", 0x3cd203b0\n"                                                          \
+    "v_mul_f64 " BHX_TA ", " BHX_DX ", " BHX_DX "\n"                                                \
+    "v_mul_f64 " BHX_TB ", " BHX_DY ", " BHX_DY "\n"                                                \
+    "s_cmp_lt_u32 s46, 0xc7dfc50\n"                                 /* 1e-15 < m < 2^150 for sure */ \
+    "s_cbranch_scc0 Lodd" T "_%=\n"                                                                 \
+    "v_add_f64 " BHX_D2 ", " BHX_TA ", " BHX_TB "\n"                                                \
+    "s_cmp_lt_i32 " CS ", 0\n"                                                                      \
+    "s_cbranch_scc1 Lleaf" T "_%=\n"                                                                \
+    "v_cmpx_le_f64_e32 vcc, " THR ", " BHX_D2 "\n"                  /* project.cu:634, 643 */       \
+    "s_andn2_b64 s[70:71], s[64:65], vcc\n"                                                         \
+    "Ltake" T "_%=:\n"                                                                              \
+    "s_cbranch_execz Lend" T "_%=\n"                                                                \
+    "v_cmp_ge_f64 vcc, " BHX_TA ", %[tiny2]\n"                                                      \
+    "v_cmp_ge_f64 s[44:45], " BHX_TB ", %[tiny2]\n"                                                 \
+    "s_and_b64 vcc, vcc, s[44:45]\n"                                                                \
+    "v_cmp_le_f64 s[44:45], " BHX_D2 ", %[huge]\n"                                                  \
+    "s_and_b64 vcc, vcc, s[44:45]\n"                                                                \
+    "s_and_b64 vcc, vcc, %[lsafe]\n"                                                                \
+    "s_andn2_b64 s[44:45], exec, vcc\n"                                                             \
+    "s_cbranch_scc1 Lgen" T "_%=\n"                                                                 \
+    BHX_FAST(M)                                                                                     \
+    "Lend" T "_%=:\n"
+#define BHX_STUBS(M, MLO, MHI, THR, CS, OS, T, COMPAT_CMP)                                          \
+    "Lleaf" T "_%=:\n"                                              /* project.cu:623-626, 646 */   \
+    "v_cmpx_ne_u32_e32 vcc, " OS ", %[body]\n"                                                      \
+    COMPAT_CMP(OS)                                                                                  \
+    "s_branch Ltake" T "_%=\n"                                                                      \
+    "Lodd" T "_%=:\n"                                               /* the exact empty test, then the node as above */ \
+    "v_mov_b32 v50, " MLO "\n v_mov_b32 v51, " MHI "\n"                                             \
+    "v_cmp_le_f64 vcc, " BHX_TG ", %[eps]\n"                                                        \
+    "s_nop 1\n"                                                                                     \
+    "s_cbranch_vccnz Lend" T "_%=\n"                                                                \
+    "v_add_f64 " BHX_D2 ", " BHX_TA ", " BHX_TB "\n"                                                \
+    "s_cmp_lt_i32 " CS ", 0\n"                                                                      \
+    "s_cbranch_scc1 LleafG" T "_%=\n"                                                               \
+    "v_cmpx_le_f64_e32 vcc, " THR ", " BHX_D2 "\n"                                                  \
+    "s_andn2_b64 s[70:71], s[64:65], vcc\n"                                                         \
+    "s_branch LgenE" T "_%=\n"                                                                      \
+    "LleafG" T "_%=:\n"                                                                             \
+    "v_cmpx_ne_u32_e32 vcc, " OS ", %[body]\n"                                                      \
+    COMPAT_CMP(OS)                                                                                  \
+    "LgenE" T "_%=:\n"                                                                              \
+    "s_cbranch_execz Lend" T "_%=\n"                                                                \
+    "Lgen" T "_%=:\n"                                                                               \
+    BHX_GENERIC(M)                                                                                  \
+    "s_branch Lend" T "_%=\n"
+#define BHX_COMPAT_ON(OS) "v_cmpx_ne_u32_e32 vcc, " OS ", %[alt]\n"
+#define BHX_COMPAT_OFF(OS) ""
+#define BHX_PUSH                                                                                    \
+    "s_nop 3\n"                                                                                     \
+    "v_writelane_b32 v52, s66, m0\n v_writelane_b32 v53, s67, m0\n"                                 \
+    "v_writelane_b32 v54, s64, m0\n v_writelane_b32 v55, s65, m0\n"                                 \
+    "s_add_u32 m0, m0, 1\n"
+#define BHX_LOOP(COMPAT_CMP)                                                                        \
+    "s_mov_b32 m0, 0\n"                                                                             \
+    "s_mov_b32 s66, %[quad]\n s_mov_b32 s67, 3\n s_mov_b64 s[64:65], %[live]\n"                     \
+    BHX_GUARD_INIT                                                                                  \
+    "Lloop_%=:\n"                                                   /* the pair that holds child s67 of quad s66 */ \
+    BHX_GUARD                                                                                       \
+    "s_and_b32 s46, s67, -2\n"                                                                      \
+    "s_add_u32 s46, s66, s46\n"                                                                     \
+    "s_lshl_b32 s47, s46, 5\n"                                                                      \
+    "s_load_dwordx16 s[24:39], %[gd], s47\n"                                                        \
+    "s_lshl_b32 s47, s46, 3\n"                                                                      \
+    "s_load_dwordx4 s[40:43], %[ld], s47\n"                                                         \
+    "s_mov_b64 exec, s[64:65]\n"                                                                    \
+    "s_bitcmp1_b32 s67, 0\n"                                                                        \
+    "s_waitcnt lgkmcnt(0)\n"                                                                        \
+    "s_cbranch_scc0 Llo_%=\n"                                                                       \
+    "s_sub_u32 s67, s67, 1\n"                                                                       \
+    BHX_EVAL("s[32:33]", "s[34:35]", "s[36:37]", "s36", "s37", "s[38:39]", "s42", "s43", "H", COMPAT_CMP) \
+    "s_cmp_eq_u64 s[70:71], 0\n"                                                                    \
+    "s_cbranch_scc1 LloE_%=\n"                                                                      \
+    BHX_PUSH                                                        /* the level continues at its even child */ \
+    "s_mov_b32 s66, s42\n s_mov_b32 s67, 3\n s_mov_b64 s[64:65], s[70:71]\n"                        \
+    "s_branch Lloop_%=\n"                                                                           \
+    "LloE_%=:\n"                                                                                    \
+    "s_mov_b64 exec, s[64:65]\n"                                                                    \
+    "Llo_%=:\n"                                                                                     \
+    "s_sub_u32 s67, s67, 1\n"                                                                       \
+    BHX_EVAL("s[24:25]", "s[26:27]", "s[28:29]", "s28", "s29", "s[30:31]", "s40", "s41", "L", COMPAT_CMP) \
+    "s_cmp_eq_u64 s[70:71], 0\n"                                                                    \
+    "s_cbranch_scc1 Lnext_%=\n"                                                                     \
+    "s_cmp_lt_i32 s67, 0\n"                                                                         \
+    "s_cbranch_scc1 Ltail_%=\n"                                     /* an exhausted level is not stacked */ \
+    BHX_PUSH                                                                                        \
+    "Ltail_%=:\n"                                                                                   \
+    "s_mov_b32 s66, s40\n s_mov_b32 s67, 3\n s_mov_b64 s[64:65], s[70:71]\n"                        \
+    "s_branch Lloop_%=\n"                                                                           \
+    "Lnext_%=:\n"                                                                                   \
+    "s_cmp_gt_i32 s67, -1\n"                                                                        \
+    "s_cbranch_scc1 Lloop_%=\n"                                                                     \
+    "s_sub_u32 m0, m0, 1\n"                                         /* SCC = borrow: the stack was empty */ \
+    "s_cbranch_scc1 Ldone_%=\n"                                                                     \
+    "s_lshl_b64 exec, 1, m0\n"                                                                      \
+    "v_readfirstlane_b32 s66, v52\n v_readfirstlane_b32 s67, v53\n"                                 \
+    "v_readfirstlane_b32 s64, v54\n v_readfirstlane_b32 s65, v55\n"                                 \
+    "s_branch Lloop_%=\n"                                                                           \
+    BHX_STUBS("s[36:37]", "s36", "s37", "s[38:39]", "s42", "s43", "H", COMPAT_CMP)                  \
+    BHX_STUBS("s[28:29]", "s28", "s29", "s[30:31]", "s40", "s41", "L", COMPAT_CMP)                  \
+    "Ldone_%=:\n"                                                                                   \
+    "s_mov_b64 exec, -1\n"                                          /* (the kernel runs the traversal with all lanes enabled) */
+#define BHX_OPERANDS                                                                                \
+    : [fx] "+v"(fx), [fy] "+v"(fy)                                                                  \
+    : [px] "v"(px), [py] "v"(py), [gm] "v"(gm), [body] "v"(body), [alt] "v"(alt), [gd] "s"(gd), [ld] "s"(ld),           \
+      [tiny2] "s"(tiny2), [huge] "s"(huge), [eps] "s"(eps), [lsafe] "s"(lanes_safe), [quad] "s"(quad), [live] "s"(live) \
+    : BHX_GUARD_CLOBBER                                                                             \
+      "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39",   \
+      "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s64", "s65", "s66", "s67", "s70", "s71",   \
+      "m0", "vcc", "scc", "memory",                                                                 \
+      "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",   \
+      "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55"
+
+// Walks the subtree below quad `quad` (node id of its first sibling) for the lanes in `live`, visiting children 3,2,1,0 and
+// every subtree before the next sibling: each lane's terms are added in the reference's order (project.cu:662-668).
+// gd / ld: the node and link arrays; byte offsets are 32-bit (the caller checks node_cap * 32 < 4 GiB).
+template <bool COMPAT>
+__device__ __forceinline__ void walk_exact_asm(const char __attribute__((address_space(4))) *gd,
+                                               const char __attribute__((address_space(4))) *ld, int32_t quad, uint64_t live,
+                                               uint64_t lanes_safe, double px, double py, double gm, int32_t body, int32_t alt,
+                                               double &fx, double &fy)
+{
+    const double tiny2 = 0x1p-400, huge = 0x1p400, eps = 1e-15;
+    if constexpr (COMPAT) asm volatile(BHX_LOOP(BHX_COMPAT_ON) BHX_OPERANDS);
+    else asm volatile(BHX_LOOP(BHX_COMPAT_OFF) BHX_OPERANDS);
+}
+
 // THR (the product): the node's `size` slot holds the EXACT d2 threshold of its acceptance test (exact_walk_threshold,
 // bh_tree.hpp), so the test is one comparison instead of sqrt + add + divide -- the same decisions bit for bit -- and the
 // square root and the three divisions of an accepted term run only on nodes some lane accepts, through the SAME
@@ -28,11 +294,8 @@ extern "C" __device__ int exact_writelane_i32(int value, int lane, int old) __as
 // dy / d share the refined reciprocal of d.  Any lane outside those ranges sends the wave through the plain expressions
 // for that node.  THR = false (BH_FLAG_WALK_PORTABLE; the node kernel then stores the size) is the walk written as the
 // reference writes it: tests/test_gpu_exact.py holds the two bit-identical on every input, extreme ranges included.
-// ASM (the product, with THR): the evaluation of one node as ONE block of gfx950 assembly -- the lanes that walk the node,
-// then those that accept it, then those that take its term are selected by narrowing EXEC (s_and_b64 / the compare's
-// mask) instead of by per-lane booleans, the three Newton chains (sqrt, 1 / d2, 1 / d) are interleaved, and nothing is
-// copied between registers: 50 vector instructions for an accepted node against the compiler's 66 for the C++ statement
-// of the same operations (THR without ASM: the counting variant runs it, and the three are compared bit for bit).
+// ASM (the product, with THR): the traversal below the root is walk_exact_asm above; THR without ASM is the C++ statement
+// of the same operations (the counting variant runs it), and the three are compared bit for bit.
 template <bool COMPAT, bool STATS, bool THR = true, bool ASM = false>
 __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
     const NodeD *__restrict__ gd, const LinkD *__restrict__ ld, const uint32_t *__restrict__ perm,
@@ -70,109 +333,6 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
     // lanes that must open it
     auto eval = [&](const NodeD q, const LinkD k, uint64_t live, int32_t &child_out) -> uint64_t {
         child_out = k.child;
-        if (ASM) {
-            // status 1: some lane that takes the node has an operand outside the ranges -- nothing was added, the C++
-            // statement below evaluates the node with the plain expressions
-            int32_t status;
-            uint64_t open, sav, tm;
-            double dx, dy, d2, ta, tb, tc, td, te, tf, tg;
-            asm volatile(
-                // the node's mass from its high word: below 1e-15 = 0x3CD203AF'9EE75616 the node is empty (project.cu:617)
-                // -- every second child of the tree's last level --, above it and below 2^150 the short sequences apply;
-                // the one high word in between, negative numbers and NaNs go to the C++ statement
-                "s_mov_b64 %[sav], exec\n\t"
-                "s_mov_b32 %[st], 0\n\t"
-                "s_mov_b64 %[open], 0\n\t"
-                "s_cmp_lt_u32 %[mhi], 0x3cd203af\n\t"
-                "s_cbranch_scc1 9f\n\t"
-                "s_sub_u32 %[st], %[mhi], 0x3cd203b0\n\t"
-                "s_cmp_lt_u32 %[st], 0xc7dfc50\n\t"             // 0x49500000 - 0x3cd203b0
-                "s_mov_b32 %[st], 0\n\t"
-                "s_cbranch_scc0 8f\n\t"
-                "s_and_b64 exec, exec, %[live]\n\t"
-                "v_add_f64 %[dx], %[cx], -%[px]\n\t"
-                "v_add_f64 %[dy], %[cy], -%[py]\n\t"
-                "v_mul_f64 %[ta], %[dx], %[dx]\n\t"
-                "v_mul_f64 %[tb], %[dy], %[dy]\n\t"
-                "v_add_f64 %[d2], %[ta], %[tb]\n\t"
-                "s_cmp_lt_i32 %[child], 0\n\t"
-                "s_cbranch_scc1 1f\n\t"
-                // subdivided cell: lanes at or beyond the threshold accept it (project.cu:634, 643), the others open it
-                "v_cmp_ge_f64 vcc, %[d2], %[thr]\n\t"
-                "s_andn2_b64 %[open], exec, vcc\n\t"
-                "s_and_b64 exec, exec, vcc\n\t"
-                "s_cbranch_execz 9f\n\t"
-                "s_branch 2f\n"
-                "1:\n\t"
-                // leaf: every lane takes it but its occupant (project.cu:623-626, 646)
-                "s_mov_b64 %[open], 0\n\t"
-                "v_cmp_ne_u32 vcc, %[occ], %[body]\n\t"
-                "v_cmp_ne_u32 %[tm], %[occ], %[alt]\n\t"
-                "s_and_b64 vcc, vcc, %[tm]\n\t"
-                "s_and_b64 exec, exec, vcc\n\t"
-                "s_cbranch_execz 9f\n"
-                "2:\n\t"
-                // the operand ranges of the short sequences, over the lanes that take the node
-                "v_cmp_ge_f64 vcc, %[ta], %[tiny2]\n\t"
-                "v_cmp_ge_f64 %[tm], %[tb], %[tiny2]\n\t"
-                "s_and_b64 vcc, vcc, %[tm]\n\t"
-                "v_cmp_le_f64 %[tm], %[d2], %[huge]\n\t"
-                "s_and_b64 vcc, vcc, %[tm]\n\t"
-                "s_and_b64 vcc, vcc, %[lsafe]\n\t"
-                "s_andn2_b64 %[tm], exec, vcc\n\t"
-                "s_cbranch_scc1 8f\n\t"
-                // sqrt(d2) in td (y, g, h: one coupled step, two residual corrections), 1 / d2 in tb, G m_i m in tc
-                "v_rsq_f64 %[ta], %[d2]\n\t"
-                "v_rcp_f64 %[tb], %[d2]\n\t"
-                "v_mul_f64 %[tc], %[gm], %[m]\n\t"
-                "v_mul_f64 %[td], %[d2], %[ta]\n\t"
-                "v_mul_f64 %[te], %[ta], 0.5\n\t"
-                "v_fma_f64 %[ta], -%[d2], %[tb], 1.0\n\t"
-                "v_fma_f64 %[tf], -%[te], %[td], 0.5\n\t"
-                "v_fma_f64 %[tb], %[tb], %[ta], %[tb]\n\t"
-                "v_fma_f64 %[td], %[td], %[tf], %[td]\n\t"
-                "v_fma_f64 %[te], %[te], %[tf], %[te]\n\t"
-                "v_fma_f64 %[ta], -%[d2], %[tb], 1.0\n\t"
-                "v_fma_f64 %[tf], -%[td], %[td], %[d2]\n\t"
-                "v_fma_f64 %[tb], %[tb], %[ta], %[tb]\n\t"
-                "v_fma_f64 %[td], %[tf], %[te], %[td]\n\t"
-                "v_mul_f64 %[ta], %[tc], %[tb]\n\t"
-                "v_fma_f64 %[tf], -%[td], %[td], %[d2]\n\t"
-                "v_fma_f64 %[tg], -%[d2], %[ta], %[tc]\n\t"
-                "v_fma_f64 %[td], %[tf], %[te], %[td]\n\t"
-                "v_fma_f64 %[ta], %[tg], %[tb], %[ta]\n\t"      // ta = (G m_i m) / d2, project.cu:651
-                "v_add_f64 %[td], %[td], %[eps]\n\t"            // td = sqrt(d2) + 1e-15, project.cu:634
-                "v_rcp_f64 %[tb], %[td]\n\t"
-                "s_nop 0\n\t"
-                "v_fma_f64 %[tc], -%[td], %[tb], 1.0\n\t"
-                "v_fma_f64 %[tb], %[tb], %[tc], %[tb]\n\t"
-                "v_fma_f64 %[tc], -%[td], %[tb], 1.0\n\t"
-                "v_fma_f64 %[tb], %[tb], %[tc], %[tb]\n\t"
-                "v_mul_f64 %[tc], %[dx], %[tb]\n\t"
-                "v_mul_f64 %[te], %[dy], %[tb]\n\t"
-                "v_fma_f64 %[tf], -%[td], %[tc], %[dx]\n\t"
-                "v_fma_f64 %[tg], -%[td], %[te], %[dy]\n\t"
-                "v_fma_f64 %[tc], %[tf], %[tb], %[tc]\n\t"      // dx / d, project.cu:654
-                "v_fma_f64 %[te], %[tg], %[tb], %[te]\n\t"      // dy / d, project.cu:655
-                "v_mul_f64 %[tc], %[ta], %[tc]\n\t"
-                "v_mul_f64 %[te], %[ta], %[te]\n\t"
-                "v_add_f64 %[fx], %[fx], %[tc]\n\t"
-                "v_add_f64 %[fy], %[fy], %[te]\n\t"
-                "s_branch 9f\n"
-                "8:\n\t"
-                "s_mov_b32 %[st], 1\n"
-                "9:\n\t"
-                "s_mov_b64 exec, %[sav]"
-                : [st] "=&s"(status), [open] "=&s"(open), [sav] "=&s"(sav), [tm] "=&s"(tm), [dx] "=&v"(dx), [dy] "=&v"(dy),
-                  [d2] "=&v"(d2), [ta] "=&v"(ta), [tb] "=&v"(tb), [tc] "=&v"(tc), [td] "=&v"(td), [te] "=&v"(te),
-                  [tf] "=&v"(tf), [tg] "=&v"(tg), [fx] "+v"(fx), [fy] "+v"(fy)
-                : [live] "s"(live), [cx] "s"(q.cx), [cy] "s"(q.cy), [m] "s"(q.m), [mhi] "s"(__double2hiint(q.m)), [thr] "s"(q.size), [child] "s"(k.child),
-                  [occ] "s"(k.occ), [px] "v"(p.x), [py] "v"(p.y), [gm] "v"(Gm), [body] "v"(body_lo),
-                  [alt] "v"(COMPAT ? body_alt : body_lo), [tiny2] "s"(kTiny * kTiny), [huge] "s"(kHuge), [eps] "s"(1e-15),
-                  [lsafe] "s"(lanes_safe)
-                : "vcc", "scc");
-            if (status == 0) return open;
-        }
         if (q.m <= 1e-15) return 0;                // project.cu:617
         const bool mine = (live >> lane) & 1ull;
         const bool leaf = k.child < 0;             // all four children -1, project.cu:623-626
@@ -195,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
         if (mine && accept && !self) {
             const double num = Gm * q.m;
             bool fast = false;
-            if (THR && !ASM) {
+            if (THR) {
                 const bool safe = lane_safe && q.m <= kLaneHi && fabs(dx) >= kTiny && fabs(dy) >= kTiny && d2 <= kHuge;
                 fast = __ballot(!safe) == 0ull;    // (of the lanes that take this node)
             }
@@ -233,16 +393,8 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
                 if (THR) d = sqrt(d2) + 1e-15;
                 const double f = num / d2;             // project.cu:651
                 const double ux = dx / d, uy = dy / d; // project.cu:654-655
-                if (ASM) {
-                    // (fx and fy are written by assembly only in this kernel -- here under the taking lanes' EXEC, as the
-                    // compiler has it in this branch: with a C++ `+=` beside the block above it shuttles both sums
-                    // between two register pairs on every visit, eight v_mov_b64)
-                    asm volatile("v_add_f64 %[fx], %[fx], %[tx]\n\tv_add_f64 %[fy], %[fy], %[ty]"
-                                 : [fx] "+v"(fx), [fy] "+v"(fy) : [tx] "v"(f * ux), [ty] "v"(f * uy));
-                } else {
-                    fx += f * ux;
-                    fy += f * uy;
-                }
+                fx += f * ux;
+                fy += f * uy;
             }
         }
         if (STATS) {
@@ -289,6 +441,17 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
     v4i ka = {};
     bool have_pair = false;
     bool more = cur_c >= 0;
+    if constexpr (ASM) {
+        if (more) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+            walk_exact_asm<COMPAT>((const char __attribute__((address_space(4))) *)gd,
+                                   (const char __attribute__((address_space(4))) *)ld, cur_quad, cur_live, lanes_safe, p.x, p.y,
+                                   Gm, body_lo, COMPAT ? body_alt : body_lo, fx, fy);
+#pragma clang diagnostic pop
+        }
+        more = false;
+    }
     while (more) {
         if (!have_pair) {
             const int32_t base = cur_quad + (cur_c & ~1);
@@ -343,14 +506,6 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
         }
     }
 
-    if (ASM) {
-        // (the epilogue stores {fx, fy} as one 16-byte tuple; left to itself the register allocator keeps that tuple through
-        // the loop and moves the sums in and out of it around every assembly block -- eight v_mov_b64 per visited node.  One
-        // explicit copy here ends the loop's registers' life)
-        double ox, oy;
-        asm volatile("v_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(ox), "=&v"(oy) : "v"(fx), "v"(fy));
-        fx = ox; fy = oy;
-    }
     double2 np = p;
     if (valid) {
         force_out[body] = double2{fx, fy};

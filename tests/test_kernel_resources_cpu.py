@@ -137,6 +137,40 @@ def test_every_fp64_assembly_walk_kernel_has_no_scratch_no_spills_and_fits_its_c
         assert r["scratch"] == 0 and r["vgpr_spill"] == 0, (name, r)
 
 
+EXACT_KERNEL = re.compile(r"_ZN2bh17walk_exact_kernelILb([01])ELb([01])ELb([01])ELb([01])EEEv")    # <COMPAT, STATS, THR, ASM>
+
+
+def test_every_bit_exact_assembly_walk_kernel_has_no_scratch_no_spills_and_fits_its_ceilings(engine_asm):
+    """walk_exact_asm (csrc/bh_walk_exact.hpp, round 4) pins s24..s49, s64..s71 and v32..v55.  Both instantiations the
+    launcher reaches (reference_compat on / off): no scratch, no spills, <= 80 SGPRs and <= 64 VGPRs (8 resident waves per
+    SIMD); the loop in the code object is the hand-written one -- one 16-dword request per pair of children, the threshold
+    compare narrowing EXEC, the compiler's division expansion only out of line."""
+    ks = {}
+    for m in re.finditer(r"\.name:\s+(_ZN2bh17walk_exact_kernel\S+)\n", engine_asm):
+        meta = engine_asm[m.start():m.start() + 3000]
+        val = lambda key: int(re.search(key + r":\s+(\d+)", meta).group(1))
+        ks[m.group(1)] = {"sgpr": val(r"\.sgpr_count"), "vgpr": val(r"\.vgpr_count"), "sgpr_spill": val(r"\.sgpr_spill_count"),
+                          "vgpr_spill": val(r"\.vgpr_spill_count"), "scratch": val(r"\.private_segment_fixed_size"),
+                          "dynamic_stack": re.search(r"\.uses_dynamic_stack:\s+(\w+)", meta).group(1)}
+    asm = {k: v for k, v in ks.items() if EXACT_KERNEL.match(k).group(4) == "1"}
+    assert sorted(EXACT_KERNEL.match(k).group(1) for k in asm) == ["0", "1"]
+    for name, r in asm.items():
+        g = EXACT_KERNEL.match(name)
+        assert g.group(2) == "0" and g.group(3) == "1", name              # no counters; exact thresholds in the nodes
+        assert r["scratch"] == 0 and r["dynamic_stack"] == "false", (name, r)
+        assert r["sgpr_spill"] == 0 and r["vgpr_spill"] == 0, (name, r)
+        assert r["sgpr"] <= 80 and r["vgpr"] <= 64, (name, r)
+        body = engine_asm[engine_asm.index("\n" + name + ":"):]
+        body = body[:body.index("s_endpgm", body.index("Ldone_"))]
+        body = body[body.index("Lloop_"):body.rindex("Ldone_")]            # (the root is evaluated by the C++ statement)
+        assert "s_load_dwordx16 s[24:39]" in body and "s_load_dwordx4 s[40:43]" in body
+        assert body.count("v_cmpx_le_f64_e32") == 4                       # two children in line, two in the out-of-line stubs
+        assert body.count("v_div_scale_f64") == 12 and body.count("v_div_fixup_f64") == 6     # (out of line only: 2 x 3 divisions)
+        assert body.count("v_cmpx_ne_u32_e32") == (8 if g.group(1) == "1" else 4)
+    for name, r in ks.items():
+        assert r["scratch"] == 0 and r["vgpr_spill"] == 0, (name, r)
+
+
 def test_no_build_or_fp64_walk_kernel_uses_scratch(tmp_path):
     """Every kernel of the engine unit (tree build, sorts, LET, exact and fp64 walks) keeps its working set in registers
     and LDS: private_segment_fixed_size == 0 and no vector-register spills.  (Round 3: bucket_sort_kernel, whose 1,024-thread workgroups
