@@ -54,6 +54,11 @@ F64_CYCLES_PER_NODE = 4 * 5.3 + 5.3
 F64_CYCLES_PER_ACCEPTED = 17.0 + 11 * 5.3
 F64_CYCLES_PER_QUAD = 2.5 * 4.1 + 2.5 * 4.2
 F64_NODE_BYTES, F64_BODY_BYTES = 40, 92
+# BH_PRECISION_F64_EXACT walk (csrc/bh_walk_exact.hpp, walk_exact_asm), same calibrated costs.  Per evaluated (non-empty)
+# node: dx, dy, dx^2, dy^2, d2 + the threshold compare; per node some lane takes a term from: three range compares, G m_i m,
+# v_rsq_f64 + two v_rcp_f64, 30 more fp64 instructions (Newton steps, quotient corrections, products), two sums.
+EXACT_CYCLES_PER_NODE = 6 * 5.3
+EXACT_CYCLES_PER_ACCEPTED = 3 * 17.0 + (3 + 1 + 30 + 2) * 5.3
 # algorithmic bytes of one whole step per body, fp32 state -- fixed pipeline ~270 B + walk 12 + 20 U64 + 8
 SURVEY_PIPELINE_BYTES, SURVEY_WALK_FIXED_BYTES = 270, 20
 
@@ -314,7 +319,11 @@ def walk_roofline(G, cfg, mass, pos, vel, walk_ms, stats_flag, kind="f32"):
                       "cycles_per_node": F64_CYCLES_PER_NODE, "cycles_per_accepted_node": F64_CYCLES_PER_ACCEPTED,
                       "cycles_per_quad": F64_CYCLES_PER_QUAD, "clock_hz_assumed": SHADER_CLOCK_HZ}
     elif kind == "exact":
-        r["issue_frac"] = None      # (IEEE sqrt and three divisions per interaction, compiler-scheduled: no calibrated model)
+        valu = ss.wave_nodes * EXACT_CYCLES_PER_NODE + ss.wave_accepts * EXACT_CYCLES_PER_ACCEPTED
+        r["issue_frac"] = valu / simd_cycles
+        r["issue"] = {"valu_cycles_per_launch": valu, "simd_cycles_per_launch": simd_cycles, "nodes_per_launch": ss.wave_nodes,
+                      "accepted_nodes_per_launch": ss.wave_accepts, "cycles_per_node": EXACT_CYCLES_PER_NODE,
+                      "cycles_per_accepted_node": EXACT_CYCLES_PER_ACCEPTED, "clock_hz_assumed": SHADER_CLOCK_HZ}
     return r
 
 
@@ -672,6 +681,8 @@ def main():
                 leg, _, _ = timed_leg(G, cfg_e, me, pe, ve, ks, 2)
                 leg["roofline"] = walk_roofline(G, cfg_e, me, pe, ve, leg["walk_ms"], FLAG_WALK_STATS, kind="exact")
                 leg["roofline"]["kernel"] = "walk_exact_kernel"
+                if tag == "C3" and nn == 1 << 20 and kind == "plummer":
+                    leg["roofline"].update(committed_traffic("EXACT"))       # (profiles/r04_exact: this workload)
                 leg["step_roofline"] = step_roofline(leg["ms_per_step"], nn, leg["roofline"]["u64_nodes_per_body"],
                                                      leg["build_bytes_per_body"], kind="f64")
                 ex[tag] = {"workload": f"{kind}_N{nn}_theta{a.theta}_depth{md}_exact_fp64", "steps": ks, **leg}

@@ -471,9 +471,11 @@ int enqueue_build(bh_ctx *c)
 // fp64 walks (exact and throughput): bodies per wavefront for a launch of `cnt` bodies.  A wave's walk is one dependent chain
 // over the union of its bodies' walks (~900 node visits for 64 bodies, ~150 for one), and up to ~130k bodies the launch cannot
 // fill the GPU's 8,192 wave slots with 64-body waves anyway.  Measured (scripts/bpw_ab.py, profiles/r04_f64/bpw_sweep.txt): the
-// best number of waves is ~2,048 for the bit-exact walk (107 vector instructions per visit: more waves soon cost more vector
-// work than the shorter chains return) and ~4,096 for the throughput walk; the smallest power of two that stays below that, and
-// within what `partial` holds (one record per workgroup).  The bit-exact mode's results do not depend on it, bit for bit.
+// best number of waves is ~4,096 for the throughput walk: the smallest power of two that stays below that.  The bit-exact walk
+// (round 4's assembly loop, ~50 vector instructions per visit; scripts/bpw_ab.py -> profiles/r04_exact/bpw_sweep.txt): one body
+// per wave up to 4,096 bodies, from there 16 bodies per wave or what keeps the launch within ~2,048 waves (more waves than that
+// cost more vector work than the shorter chains return).  Always within what `partial` holds (one record per workgroup).  The
+// bit-exact mode's results do not depend on it, bit for bit.
 static int exact_bodies_per_wave(const bh_ctx *c, int64_t cnt)
 {
     // (the throughput walk adds a lane's terms in the order its WAVE meets them: its last bits depend on who shares the wave, like
@@ -481,9 +483,11 @@ static int exact_bodies_per_wave(const bh_ctx *c, int64_t cnt)
     if (c->fast64 && (c->cfg.flags & BH_FLAG_WALK_NO_SPLIT)) return kWave;
     int b = 1;
     if (c->exact_bpw > 0) b = c->exact_bpw;
-    else {
-        const int64_t waves = c->fast64 ? 4096 : 2048;
-        while (b < kWave && (int64_t)b * waves < cnt) b <<= 1;
+    else if (c->fast64) {
+        while (b < kWave && (int64_t)b * 4096 < cnt) b <<= 1;
+    } else if (cnt > 4096) {
+        b = 16;
+        while (b < kWave && (int64_t)b * 2048 < cnt) b <<= 1;
     }
     const int64_t room = std::max<int64_t>(1024, (c->cfg.capacity + kWave - 1) / kWave);      // records in `partial`
     while (b < kWave && (cnt + (int64_t)kWavesPerBlock * b - 1) / ((int64_t)kWavesPerBlock * b) > room) b <<= 1;

@@ -43,7 +43,7 @@ struct TreeCounters {
     unsigned long long visits, interactions;
     unsigned long long wave_nodes;   // nodes evaluated by wavefronts (one count per wave per node)
     unsigned long long wave_quads;   // sibling quads loaded by wavefronts (one count per wave per quad)
-    unsigned long long wave_accepts; // fp64 throughput walk: nodes some lane accepted (one count per wave per node)
+    unsigned long long wave_accepts; // fp64 walks: nodes some lane took a force term from (one count per wave per node)
 };
 
 }  // namespace bh

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
     const uint64_t lanes_safe = __ballot(lane_safe);
     const int32_t body_lo = (int32_t)body, body_alt = (int32_t)(-body - 2);     // (bodies < 2^31: bh_create)
     double fx = 0.0, fy = 0.0;
-    unsigned long long n_vis = 0, n_int = 0, n_wave = 0;
+    unsigned long long n_vis = 0, n_int = 0, n_wave = 0, n_acc = 0;
 
     // evaluate one node -- its record `q` and links `k` in scalar registers -- for the lanes in `live`; returns the mask of
     // lanes that must open it
@@ -400,7 +400,9 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
         if (STATS) {
             n_vis += __popcll(live);
             ++n_wave;
-            n_int += __popcll(__ballot(mine && accept && !self));
+            const uint64_t takers = __ballot(mine && accept && !self);
+            n_int += __popcll(takers);
+            n_acc += takers != 0;
         }
         if (leaf) return 0;
         return __ballot(mine && !accept);
@@ -527,6 +529,7 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
             atomicAdd(&ctr->visits, n_vis);
             atomicAdd(&ctr->interactions, n_int);
             atomicAdd(&ctr->wave_nodes, n_wave);
+            atomicAdd(&ctr->wave_accepts, n_acc);
         }
     }
 }

@@ -76,7 +76,7 @@ class BhStats:
     let_tree_ms: float = 0.0    # last let_build: global box + local tree
     let_pack_ms: float = 0.0    # last let_build: LET marking / numbering / packing
     sort_rerun_buckets: int = 0  # bucket-sort buckets whose short sort met a long run and was repeated in full (bh_sort.hpp)
-    wave_accepts: int = 0       # FLAG_WALK_STATS, Precision.F64: nodes some lane accepted, once per wavefront
+    wave_accepts: int = 0       # FLAG_WALK_STATS, fp64 precisions: nodes some lane took a term from, once per wavefront
     walk_launches: int = 0      # walk kernel launches of the last step (1, or the passes of n_threads)
 
 

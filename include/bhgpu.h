@@ -156,7 +156,7 @@ typedef struct bh_stats_t {
                                     runs of equal top bits by counting) met a run of more than 8 keys and was repeated
                                     with all byte passes, since bh_create (0 unless bodies pile up)          */
     /* ABI 4 */
-    uint64_t wave_accepts;       /* BH_FLAG_WALK_STATS, BH_PRECISION_F64: nodes some lane of the wavefront accepted, counted once
+    uint64_t wave_accepts;       /* BH_FLAG_WALK_STATS, the fp64 precisions: nodes some lane of the wavefront took a term from, counted once
                                     per wavefront -- the nodes that pay the reciprocal square root and the force (the
                                     others stop at the compare); 0 in the other precisions                          */
     uint64_t walk_launches;      /* walk kernel launches of the last bh_step / bh_compute_forces step: 1, or the passes

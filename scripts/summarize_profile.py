@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense a gpurun_out/<tag>/ profile directory (scripts/gpu_profile.sh) into profiles/<name>/:
 kernel_stats.csv (rocprofv3 --kernel-trace --stats), pmc_summary.csv (per-kernel counter means) and
-bench.json.  usage: summarize_profile.py gpurun_out/<tag> profiles/<name> [--tag C2|C4|C5|F64] [--no-latest]
+bench.json.  usage: summarize_profile.py gpurun_out/<tag> profiles/<name> [--tag C2|C4|C5|F64|EXACT] [--no-latest]
 --tag: the profile is of another configuration than the headline: its traffic goes to profiles/latest_walk_traffic_<tag>.json,
 which bench.py reads for that leg (other_configs.<tag>.roofline.traffic / secondary_f64.roofline.traffic)."""
 import collections, csv, glob, json, os, shutil, subprocess, sys
@@ -36,7 +36,7 @@ with open(f"{dst}/pmc_summary.csv", "w", newline="") as fh:
 # of the bytes read -- calibrated for THIS kernel's access pattern (wave-uniform 64-byte scalar
 # loads) with scripts/calib/fetch_calib.hip: ratio 0.50003 -- so reads = 2 * FETCH_SIZE.
 # the product walk of the run: the hand-scheduled kernel, or the C++ loop where the engine had to fall back to it
-prefix = "void bh::walk_f64_kernel" if tag == "F64" else "void bh::walk_fast_kernel"
+prefix = {"F64": "void bh::walk_f64_kernel", "EXACT": "void bh::walk_exact_kernel"}.get(tag, "void bh::walk_fast_kernel")
 names = collections.Counter()
 for (k, c, n, v) in rows:
     if k.startswith(prefix) and c == "FETCH_SIZE":
