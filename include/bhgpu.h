@@ -84,7 +84,11 @@ typedef enum bh_precision {
 #define BH_FLAG_WALK_PORTABLE (1u << 3) /* fp32 and BH_PRECISION_F64 walks: the C++ traversal loop instead of the
                                            hand-scheduled gfx950 assembly loop.  Same operations
                                            in the same order -- results are bit-identical; kept
-                                           as the readable statement of the loop and for tests. */
+                                           as the readable statement of the loop and for tests.
+                                           BH_PRECISION_F64_EXACT: the walk written as the reference
+                                           writes it (sqrt, size / d < theta, three divisions per
+                                           term; the nodes then carry sizes instead of exact d2
+                                           thresholds) -- bit-identical again.                  */
 
 /* Replaces the compile-time configuration of project.cu:1-11, 27-35, 60-62. */
 typedef struct bh_config {
