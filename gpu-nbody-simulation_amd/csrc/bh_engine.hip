@@ -285,14 +285,19 @@ int enqueue_build_t(bh_ctx *c)
                           && c->sort_pack;
         // bucket sort (bh_sort.hpp): one counting pass by splitters from the previous build + one in-LDS sort per bucket
         // (exact modes and BH_HILBERT=0 too since round 3: the splitters only have to be sorted, whatever curve the keys follow)
-        const bool bucket = pack && n >= 2 && n <= kBucketMaxNBig && (c->sort_bucket == 2 || (c->sort_bucket == 1 && c->samples_n == n));
+        // a launch of up to 4,096 keys is ONE bucket: no splitters, no counting pass (three launches of ~5 us less), the first build
+        // included.  (One workgroup's LDS holds 12,288 keys, but at twelve keys per thread its chain of passes is longer than the
+        // counting pass it saves: N = 12,288 measured 0.100 ms per build this way against 0.090 at N = 16,384 the other way.
+        // BH_SORT_BUCKET=2 keeps the splitter path at every size, for the tests that compare it with the LSD passes.)
+        const bool single = pack && n >= 2 && n <= 4 * kBsThreads && c->sort_bucket == 1;
+        const bool bucket = !single && pack && n >= 2 && n <= kBucketMaxNBig && (c->sort_bucket == 2 || (c->sort_bucket == 1 && c->samples_n == n));
         const int nb = (n <= kBucketMaxN) ? kBuckets : kBucketsBig;
         // sample positions behind the splitters: two per bucket where the key workgroups run long enough to hide the
         // sample workgroups (256 buckets: above 262k bodies; 1,024 buckets: above 3M), one per bucket otherwise
         const int ns = (nb == kBuckets) ? ((n > (int64_t)1 << 18) ? 2 * kBuckets : kBuckets)
                                         : ((n > (int64_t)3 << 20) ? kMaxSplitSamples : kBucketsBig);
         static_assert(kBucketMaxN == (int64_t)1 << 20 && kBucketMaxNBig == (int64_t)1 << 22, "BASELINE configs 3 and 4 fit");
-        c->last_sort_bucket = bucket; c->last_sort_packed = pack;
+        c->last_sort_bucket = bucket || single; c->last_sort_packed = pack;
         {
             const unsigned nkb = blocks_for(n, kBlock);
             auto keys_launch = [&](auto hil, auto pk, auto fs) {
@@ -316,7 +321,11 @@ int enqueue_build_t(bh_ctx *c)
         if (c->time_groups) (void)hipEventRecord(c->ev_grp[0], st);
         const unsigned nbl = blocks_for(n, ITEMS == kItems ? kSortTile : TILE);
         int cur = 0;
-        if (bucket) {
+        if (single) {
+            hipLaunchKernelGGL(bucket_sort_kernel, dim3(1), dim3(kBsThreads), 0, st, c->keys[0], c->keys[1], c->vals[1],
+                               nullptr, nullptr, &c->ctr->sort_spills, &c->ctr->sort_reruns, (int)n);
+            cur = 1;
+        } else if (bucket) {
             constexpr int SI = (ITEMS == kItems ? kSortItems : ITEMS);
             auto pass = [&](auto bits_tag) {
                 constexpr int NBITS = decltype(bits_tag)::value;
@@ -337,7 +346,7 @@ int enqueue_build_t(bh_ctx *c)
             };
             if (nb == kBuckets) pass(std::integral_constant<int, 8>{}); else pass(std::integral_constant<int, 10>{});
             hipLaunchKernelGGL(bucket_sort_kernel, dim3(nb), dim3(kBsThreads), 0, st, c->keys[1], c->keys[0], c->vals[0],
-                               c->bsum_sort, c->bsum_sort + kBucketStartOffset, &c->ctr->sort_spills, &c->ctr->sort_reruns);
+                               c->bsum_sort, c->bsum_sort + kBucketStartOffset, &c->ctr->sort_spills, &c->ctr->sort_reruns, 0);
             cur = 0;
         } else {
             // kSortBits-wide digits, wave-private ranking, digit-sorted write-out

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(kBsThreads) void bucket_sort_kernel(uint64_t *__res
                                                                   const uint32_t *__restrict__ bucket_total,
                                                                   const uint32_t *__restrict__ bucket_start,
                                                                   uint32_t *__restrict__ spills,
-                                                                  uint32_t *__restrict__ reruns)
+                                                                  uint32_t *__restrict__ reruns, int single_m)
 {
     __shared__ uint64_t skey[kBucketCap];
     __shared__ uint32_t woff[kBsWaves][kDigits];
@@ -609,8 +609,10 @@ __global__ __launch_bounds__(kBsThreads) void bucket_sort_kernel(uint64_t *__res
     __shared__ uint32_t s_flag;
     const int t = threadIdx.x, w = wave_id(), l = lane_id();
     // where this bucket starts and how many keys it holds: the counting pass's scatter left both (wave-uniform loads)
-    const int64_t start = bucket_start[blockIdx.x];
-    const int m = (int)bucket_total[blockIdx.x];
+    // (bucket_total == nullptr: a launch of at most kBucketCap keys is ONE bucket -- the keys as keys_kernel left them, no
+    // counting pass in front: three launches less for the small launches whose builds are chains of 5 us launches)
+    const int64_t start = bucket_total ? (int64_t)bucket_start[blockIdx.x] : 0;
+    const int m = bucket_total ? (int)bucket_total[blockIdx.x] : single_m;
     if (m == 0) return;
     uint64_t *in = bucketed + start;
     uint64_t *ko = kout + start;

@@ -1336,7 +1336,9 @@ __global__ __launch_bounds__(kBlock) void com_up_kernel(NodeD *__restrict__ gd, 
 // consecutive pre-order ranks holds whole subtrees, the cells it cannot finish are one chain of ancestors, lists of those chains
 // are finished over 64 x larger ranges per launch -- once as a separate kernel and once started inside nodes_exact_kernel:
 // 107 and 136 us against these 112, each bitwise equal; and two depths per launch, the shallower one recomputing its
-// subdivided children from the grandchildren: build 0.277 ms against 0.257.  profiles/r04_f64/com_ab.txt says where the time went.)
+// subdivided children from the grandchildren: build 0.277 ms against 0.257.  profiles/r04_f64/com_ab.txt says where the time went.
+// And for the smallest trees ONE workgroup, a barrier per depth: 0.120 ms per step at N = 1,024 against the climb's 0.121, 0.199 against
+// 0.155 at N = 2,048 -- a level is a round trip either way.)
 __global__ __launch_bounds__(kBlock) void com_level_kernel(NodeD *__restrict__ gd, const int32_t *__restrict__ self_node,
                                                             const int32_t *__restrict__ cell_depth,
                                                             const TreeCounters *__restrict__ ctr, int64_t internal_cap,

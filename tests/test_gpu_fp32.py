@@ -211,6 +211,36 @@ def test_bucket_sort_equals_the_lsd_sort(monkeypatch, kind, n, md, precision):
         assert spills[0] == 0                                      # steady motion: every bucket fits on chip
 
 
+@pytest.mark.parametrize("precision", ["f32", "exact", "f64"])
+@pytest.mark.parametrize("n,md", [(2, 5), (63, 10), (1024, 10), (1025, 21), (4096, 4), (4096, 21), (4097, 21)])
+def test_small_launches_are_one_bucket(monkeypatch, n, md, precision):
+    """Round 4: a launch of at most 4,096 bodies is sorted by bucket_sort_kernel alone -- one workgroup, the keys as
+    keys_kernel left them, no splitters and no counting pass, from the first build on.  Same stable order as the LSD passes
+    (BH_SORT_BUCKET=0) and as the splitter path (=2): tree, forces and a moving trajectory BITWISE the same, depth-cap cells
+    that hold many equal keys included (max_depth 4 at 4,096 bodies: 64 cells of 64)."""
+    m, p, v = _sort_case("uniform", n)
+    prec = {"f32": G.Precision.F32, "exact": G.Precision.F64_EXACT, "f64": G.Precision.F64}[precision]
+    res = []
+    for mode in ("1", "0", "2"):
+        monkeypatch.setenv("BH_SORT_BUCKET", mode)
+        with engine(n, max_depth=md, reference_compat=precision != "f32", precision=prec) as e:
+            e.upload(p, v, m)
+            f = e.compute_forces()                                 # (mode 1: one bucket already in the first build)
+            nodes, depth = e.export_tree()
+            e.step(5)
+            e.build_tree()
+            nodes2, depth2 = e.export_tree()
+            res.append((f, nodes, depth, nodes2, depth2) + e.download())
+            assert e.stats().sort_spill_buckets == 0
+    for other in res[1:]:
+        for x, y in zip(res[0], other):
+            if x.dtype.names:                                      # (the exported tree: a record array)
+                assert all(np.array_equal(x[f], y[f], equal_nan=True) for f in x.dtype.names)
+            else:
+                assert np.array_equal(x, y, equal_nan=True)
+    assert np.isfinite(res[0][5]).all()
+
+
 def test_bucket_sort_with_small_build_tiles_above_1m_bodies(monkeypatch):
     """BH_BUILD_ITEMS=2 (512-key tiles) is honoured up to 4M bodies, and between 1M and 4M the bucket
     pass counts 1,024 buckets per tile -- 2 words per body, which the counting scratch (sized for 2,048-key tiles)
