@@ -61,6 +61,9 @@ struct bh_ctx {
     int64_t internal_cap = 0, node_cap = 0;
     int sort_passes = 0;
     bool state64 = false;          // fp64 state arrays: exact and mixed precision
+    int64_t bfs_max = 12288;       // bit-exact walk: one wavefront per body (walk_exact_bfs_kernel) for launches up to here (BH_EXACT_BFS_MAX;
+                                   // walk ms against the cooperative walk: 0.021 / 0.072 at N = 1,024, 0.042 / 0.108 at 4,096, 0.126 / 0.223
+                                   // at 8,192, 0.180 / 0.221 at 12,288, 0.241 / 0.212 at 16,384)
     int exact_bpw = 0;             // BH_EXACT_BPW: bodies per wavefront in the fp64 walks (0 = by launch size; 64 = rounds 1-3)
     int walk_split = 0;            // 0 = automatic
     bool walk_asm = true;          // BH_WALK_ASM=0: the C++ loop everywhere (A/B)
@@ -515,6 +518,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
     const bool want_partial = integrate && !to_sorted && lo == 0 && hi == c->n;
     double *partial = want_partial ? c->partial : nullptr;
     int per_partial = kBlock;
+    int partial_records = -1;                                      // (a walk whose workgroups do not take a fixed number of bodies says so itself)
     // N_THREADS (project.cu:5-7, 703: `body_i += N_THREADS`): at most that many bodies are walked at a time -- the
     // range is taken in passes of n_threads bodies, rounded up to whole 256-thread workgroups, one launch after the
     // other on the stream, as the reference's threads take their bodies one after the other.  0 (the default):
@@ -568,6 +572,29 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
             else           { if (deep) pick(Fz{}, T{}); else pick(Fz{}, Fz{}); }
         }
         per_partial = per_block;
+        BH_HIP(c, hipGetLastError());
+    } else if (c->exact && c->exact_thr && !stats && c->exact_bpw == 0 && pass == hi - lo && hi - lo <= c->bfs_max &&
+               c->node_cap * (int64_t)sizeof(NodeD) < (1ll << 32)) {
+        // launches of a few thousand bodies: one wavefront per BODY, its tree breadth-first (walk_exact_bfs_kernel) -- the same
+        // bits as the cooperative walk below, which an explicit BH_EXACT_BPW, the counting variant and the portable walk keep using
+        // a workgroup = four wavefronts, each taking bodies (turn * grid + workgroup) * 4 + wave one after the other; as many
+        // workgroups as `partial` has records (at least 1,024), every wave at most 64 bodies
+        const int64_t cnt = std::min(pass, hi - lo);
+        const int64_t room = std::max<int64_t>(1024, (c->cfg.capacity + kWave - 1) / kWave);
+        const int64_t grid = std::max<int64_t>(std::min<int64_t>(blocks_for(cnt, kWavesPerBlock), room),
+                                               blocks_for(cnt, kWavesPerBlock * kBfsBodiesPerWave));
+        {
+            auto args = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), 0, c->stream, c->gd, c->ld, c->perm, (double2 *)c->pos,
+                                   (double2 *)c->vel, (const double *)c->mass, (double2 *)c->force, lo, hi, c->cfg.G, c->cfg.dt,
+                                   integrate ? 1 : 0, c->ctr, partial, slots);
+                c->walk_launches += 1;
+            };
+            const bool big = cnt > 4096;                         // (more interactions per body in larger trees: 384 terms per walk -- 52 KB of LDS per workgroup, three per CU; 512 would leave two)
+            if (c->compat) { if (big) args(walk_exact_bfs_kernel<true, 384>); else args(walk_exact_bfs_kernel<true, 256>); }
+            else           { if (big) args(walk_exact_bfs_kernel<false, 384>); else args(walk_exact_bfs_kernel<false, 256>); }
+        }
+        partial_records = (int)grid;
         BH_HIP(c, hipGetLastError());
     } else if (c->exact) {
         const int bpw = exact_bodies_per_wave(c, std::min(pass, hi - lo));
@@ -653,7 +680,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
             c->walk_launches += 1;
         }
     }
-    if (want_partial) c->partial_count = (int)blocks_for(hi - lo, per_partial);
+    if (want_partial) c->partial_count = partial_records >= 0 ? partial_records : (int)blocks_for(hi - lo, per_partial);
     if (!c->exact && lo == 0 && hi == c->n) c->group_cost_valid = true;
     return BH_OK;
 }
@@ -716,6 +743,7 @@ int bh_create(const bh_config *cfg, bh_ctx **out)
     if (const char *e = std::getenv("BH_WALK_SPLIT")) c->walk_split = std::atoi(e);
     if (const char *e = std::getenv("BH_EXACT_BPW")) { const int b = std::atoi(e); c->exact_bpw = (b >= 1 && b <= kWave && (b & (b - 1)) == 0) ? b : 0; }
     if (const char *e = std::getenv("BH_WALK_ASM")) c->walk_asm = std::atoi(e) != 0;
+    if (const char *e = std::getenv("BH_EXACT_BFS_MAX")) c->bfs_max = std::max(0, std::atoi(e));
     c->exact_thr = c->exact && !c->fast64 && c->walk_asm && !(cfg->flags & BH_FLAG_WALK_PORTABLE);
     if (const char *e = std::getenv("BH_SORT_PACK")) c->sort_pack = std::atoi(e) != 0;
     if (const char *e = std::getenv("BH_SORT_BUCKET")) c->sort_bucket = std::atoi(e);

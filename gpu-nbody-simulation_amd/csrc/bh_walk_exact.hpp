@@ -534,4 +534,233 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
     }
 }
 
+// ---- launches of a few thousand bodies: ONE WAVEFRONT PER BODY, the tree level by level ---------------------------------
+// At the reference's own sizes (config 1: 1,024 bodies) the walk above is one body per wave and ~150 node visits one
+// after the other, each a memory round trip and a 40-instruction dependent chain: 68 us for 0.1 ms of step.  But the terms
+// a body adds are independent of each other -- only the ORDER of the additions is the reference's.  So here the 64 lanes of
+// a wave walk ONE body's tree breadth-first: a queue of nodes in LDS, 64 nodes per round (vector loads), every lane decides
+// its node by the exact threshold and computes its term; an opened node appends its four children.  Every queued node
+// carries its DFS sort key -- two bits per level, child 3 first, as the reference pops them (project.cu:662-668) -- and the
+// accepted nodes of a walk are an antichain of the tree, so sorting their terms by key IS the reference's order of additions:
+// the terms are ranked by counting (<= 256 of them), permuted in LDS, and added one after the other from 0.0.  About ten
+// rounds instead of ~150 visits.  A walk whose queue or term list would overflow (theta -> 0, adversarial trees) starts
+// again through walk_exact_asm: same bits either way (tests/test_gpu_exact.py: every size from 1 to 4,096 against the
+// reference's own vectors and against the cooperative walk).
+constexpr int kBfsQueue = 256;                      // per wavefront; a ring.  Terms per walk: 256 or 384 (template)
+constexpr int kBfsBodiesPerWave = 64;              // a wave takes up to this many bodies, one after the other
+
+// one accepted term f * (dx, dy) / d (project.cu:634, 651-655): the short sequences where `safe` (the operand ranges of
+// walk_exact_kernel), the plain expressions otherwise -- the same bits
+__device__ __forceinline__ void exact_term(double dx, double dy, double d2, double num, bool safe, double &tx, double &ty)
+{
+    double f, ux, uy;
+    if (safe) {
+        const double y = __builtin_amdgcn_rsq(d2);
+        double g = d2 * y, h = y * 0.5;
+        const double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        double e = __builtin_fma(-g, g, d2);
+        h = __builtin_fma(h, r, h);
+        g = __builtin_fma(e, h, g);
+        e = __builtin_fma(-g, g, d2);
+        g = __builtin_fma(e, h, g);
+        const double dd = g + 1e-15;
+        auto recip = [](double b) {
+            double r0 = __builtin_amdgcn_rcp(b);
+            double t = __builtin_fma(-b, r0, 1.0);
+            r0 = __builtin_fma(r0, t, r0);
+            t = __builtin_fma(-b, r0, 1.0);
+            return __builtin_fma(r0, t, r0);
+        };
+        auto quot = [](double a, double b, double rb) {
+            const double q0 = a * rb;
+            const double rem = __builtin_fma(-b, q0, a);
+            return __builtin_fma(rem, rb, q0);
+        };
+        const double r2 = recip(d2), rd = recip(dd);
+        f = quot(num, d2, r2);
+        ux = quot(dx, dd, rd); uy = quot(dy, dd, rd);
+    } else {
+        const double d = sqrt(d2) + 1e-15;
+        f = num / d2;
+        ux = dx / d; uy = dy / d;
+    }
+    tx = f * ux;
+    ty = f * uy;
+}
+
+#define BH_WAVE_SYNC()                                                                              \
+    do {                                                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                      \
+        __builtin_amdgcn_wave_barrier();                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                      \
+    } while (0)
+
+template <bool COMPAT, int TERMS>
+__global__ __launch_bounds__(kBlock) void walk_exact_bfs_kernel(
+    const NodeD *__restrict__ gd, const LinkD *__restrict__ ld, const uint32_t *__restrict__ perm,
+    double2 *__restrict__ pos, double2 *__restrict__ vel, const double *__restrict__ mass,
+    double2 *__restrict__ force_out, int64_t lo, int64_t hi, double G, double dt, int integrate, TreeCounters *ctr,
+    double *__restrict__ partial, double *slots)
+{
+    __shared__ uint64_t s_meta[kWavesPerBlock][kBfsQueue];       // node id | depth << 32
+    __shared__ uint64_t s_qkey[kWavesPerBlock][kBfsQueue];
+    __shared__ uint64_t s_tkey[kWavesPerBlock][TERMS];
+    __shared__ double2 s_term[kWavesPerBlock][TERMS];
+    constexpr int kBfsTerms = TERMS;
+    if (ctr->overflow) return;
+    const int lane = lane_id(), w = wave_id();
+    constexpr double kLaneLo = 0x1p-150, kLaneHi = 0x1p150, kTiny = 0x1p-200, kHuge = 0x1p400;
+    // body k of this wave: sorted index lo + (k * gridDim.x + blockIdx.x) * 4 + w; its new position stays in lane k for the
+    // workgroup's bounds record
+    double npx = 0.0, npy = 0.0;
+    bool np_valid = false;
+    for (int turn = 0; turn < kBfsBodiesPerWave; ++turn) {
+    const int64_t s = lo + ((int64_t)turn * gridDim.x + blockIdx.x) * kWavesPerBlock + w;
+    const bool have = s < hi;                                     // wave-uniform
+    if (!have) break;
+    const int64_t body = (int64_t)perm[s];
+    const double2 p = pos[body];
+    const double mi = mass[body];
+    const double Gm = G * mi;
+    const bool lane_safe = fabs(Gm) >= kLaneLo && fabs(Gm) <= kLaneHi;
+    double fx = 0.0, fy = 0.0;
+
+    {
+        // one node for this lane: its term (take) or its children (open)
+        auto decide = [&](int32_t node, bool active, bool &take, bool &open, int32_t &child, double &tx, double &ty) {
+            take = false; open = false; child = -1; tx = 0.0; ty = 0.0;
+            if (!active) return;
+            const NodeD q = gd[node];
+            const LinkD k = ld[node];
+            if (q.m <= 1e-15) return;                             // project.cu:617
+            const bool leaf = k.child < 0;
+            const double dx = q.cx - p.x, dy = q.cy - p.y;
+            const double d2 = dx * dx + dy * dy;
+            const bool accept = leaf || (d2 >= q.size);           // the exact threshold: project.cu:634, 643
+            bool self = false;
+            if (leaf) {
+                self = ((int64_t)k.occ == body);
+                if (COMPAT) self = self || ((int64_t)k.occ + 2 == -body);   // project.cu:646
+            }
+            if (accept) {
+                if (self) return;
+                const bool safe = lane_safe && q.m <= kLaneHi && fabs(dx) >= kTiny && fabs(dy) >= kTiny && d2 <= kHuge;
+                exact_term(dx, dy, d2, Gm * q.m, safe, tx, ty);
+                take = true;
+            } else {
+                open = true; child = k.child;
+            }
+        };
+        uint32_t head = 0, tail = 1, tcount = 0;
+        bool spill = false;
+        if (lane == 0) { s_meta[w][0] = 0ull; s_qkey[w][0] = 0ull; }
+        BH_WAVE_SYNC();
+        while (head != tail && !spill) {
+            const uint32_t cnt = (tail - head < (uint32_t)kWave) ? tail - head : (uint32_t)kWave;
+            const bool active = (uint32_t)lane < cnt;
+            const uint32_t at = (head + (uint32_t)lane) & (kBfsQueue - 1);
+            const uint64_t meta = active ? s_meta[w][at] : 0ull;
+            const uint64_t key = active ? s_qkey[w][at] : 0ull;
+            head += cnt;
+            bool take, open;
+            int32_t child;
+            double tx, ty;
+            decide((int32_t)(uint32_t)meta, active, take, open, child, tx, ty);
+            const uint64_t tb = __ballot(take), ob = __ballot(open);
+            const uint32_t nt = (uint32_t)__popcll(tb), no = (uint32_t)__popcll(ob);
+            if (tcount + nt > (uint32_t)kBfsTerms || (tail - head) + 4u * no > (uint32_t)kBfsQueue) { spill = true; break; }
+            const uint64_t below = (1ull << lane) - 1ull;
+            if (take) {
+                const uint32_t at_t = tcount + (uint32_t)__popcll(tb & below);
+                s_tkey[w][at_t] = key;
+                s_term[w][at_t] = double2{tx, ty};
+            }
+            if (open) {
+                const uint32_t depth = (uint32_t)(meta >> 32) + 1u;               // the children's depth: 1 .. 31
+                const uint32_t base = tail + 4u * (uint32_t)__popcll(ob & below);
+#pragma unroll
+                for (uint32_t c = 0; c < 4; ++c) {
+                    const uint32_t q_at = (base + c) & (kBfsQueue - 1);
+                    s_meta[w][q_at] = (uint64_t)(uint32_t)(child + (int32_t)c) | ((uint64_t)depth << 32);
+                    s_qkey[w][q_at] = key | ((uint64_t)(3u - c) << (62u - 2u * depth));   // child 3 is popped first
+                }
+            }
+            tcount += nt;
+            tail += 4u * no;
+            BH_WAVE_SYNC();
+        }
+        if (!spill) {
+            // the reference's order of additions = ascending key: rank by counting, permute, add one after the other
+            // (64 terms at a time: most walks hold 100-200 terms, two to four rounds of the TERMS / 64 the list has room for)
+            double2 mt[kBfsTerms / kWave];
+            uint32_t rk[kBfsTerms / kWave];
+            const uint32_t tpad = (tcount + 3u) & ~3u;
+            if ((uint32_t)lane < tpad - tcount) s_tkey[w][tcount + (uint32_t)lane] = ~0ull;      // (pads the last group of four: never below a key)
+            BH_WAVE_SYNC();
+#pragma unroll
+            for (int k = 0; k < kBfsTerms / kWave; ++k) {
+                const uint32_t i = (uint32_t)lane + (uint32_t)(k * kWave);
+                rk[k] = 0;
+                mt[k] = double2{0.0, 0.0};
+                if ((uint32_t)(k * kWave) < tcount) {                                             // wave-uniform
+                    const uint64_t mine = (i < tcount) ? s_tkey[w][i] : 0ull;
+                    mt[k] = (i < tcount) ? s_term[w][i] : double2{0.0, 0.0};
+                    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+                    for (uint32_t j = 0; j < tpad; j += 4) {
+                        r0 += (s_tkey[w][j] < mine) ? 1u : 0u;
+                        r1 += (s_tkey[w][j + 1] < mine) ? 1u : 0u;
+                        r2 += (s_tkey[w][j + 2] < mine) ? 1u : 0u;
+                        r3 += (s_tkey[w][j + 3] < mine) ? 1u : 0u;
+                    }
+                    rk[k] = (r0 + r1) + (r2 + r3);
+                }
+            }
+            BH_WAVE_SYNC();
+#pragma unroll
+            for (int k = 0; k < kBfsTerms / kWave; ++k)
+                if ((uint32_t)lane + (uint32_t)(k * kWave) < tcount) s_term[w][rk[k]] = mt[k];
+            BH_WAVE_SYNC();
+            for (uint32_t r = 0; r < tcount; ++r) {
+                const double2 t = s_term[w][r];
+                fx += t.x;
+                fy += t.y;
+            }
+        } else {
+            // the cooperative walk for this body alone (lane 0), from the root
+            bool take, open;
+            int32_t child;
+            double tx, ty;
+            decide(0, true, take, open, child, tx, ty);
+            if (take) { fx += tx; fy += ty; }
+            const uint64_t ob = __ballot(open && lane == 0);
+            if (ob != 0ull) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+                walk_exact_asm<COMPAT>((const char __attribute__((address_space(4))) *)gd,
+                                       (const char __attribute__((address_space(4))) *)ld,
+                                       __builtin_amdgcn_readfirstlane(child), 1ull, __ballot(lane_safe) & 1ull, p.x, p.y, Gm,
+                                       (int32_t)body, COMPAT ? (int32_t)(-body - 2) : (int32_t)body, fx, fy);
+#pragma clang diagnostic pop
+            }
+        }
+    }
+
+    // (every lane holds the same sums: every lane integrates, lane 0 stores)
+    double2 np = p;
+    if (lane == 0) force_out[body] = double2{fx, fy};
+    if (integrate) {
+        // updateAccVelPos, project.cu:827-834
+        const double ax = fx / mi, ay = fy / mi;
+        double2 v = vel[body];
+        v.x += ax * dt;  v.y += ay * dt;
+        np.x += v.x * dt;  np.y += v.y * dt;
+        BH_WAVE_SYNC();                                           // (all lanes have read vel / pos of this body)
+        if (lane == 0) { vel[body] = v; pos[body] = np; }
+    }
+    if (lane == turn) { npx = np.x; npy = np.y; np_valid = true; }
+    }   // turn
+    if (partial) block_bounds_to_partial(np_valid, npx, npy, partial + 4 * (size_t)blockIdx.x, slots);
+}
+
 }  // namespace bh

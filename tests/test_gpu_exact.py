@@ -394,3 +394,35 @@ def test_threshold_walk_full_size():
     assert np.isfinite(res[0][0]).all() and np.abs(res[0][0]).max() > 0
     for x, y in zip(res[0], res[1]):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("n,theta,md,compat", [(1500, 0.5, 10, True), (1500, 1e-6, 10, True), (4096, 0.05, 21, False),
+                                                (4097, 0.5, 21, True), (6000, 0.02, 12, True), (8192, 0.5, 32, False),
+                                                (3, 0.5, 10, True), (257, 0.5, 2, True)])
+def test_one_wavefront_per_body_walk_equals_the_cooperative_walk(monkeypatch, n, theta, md, compat):
+    """Round 4: launches of up to 8,192 bodies walk the tree with ONE WAVEFRONT PER BODY, breadth-first (walk_exact_bfs_kernel):
+    every lane decides one queued node, the accepted terms carry the DFS key of their node and are added in ascending key
+    order -- the reference's order of additions.  BITWISE the same forces and trajectory as the cooperative walk (an explicit
+    BH_EXACT_BPW keeps it) and as the walk written as the reference writes it; theta -> 0 and dense depth-cap trees overflow
+    the 256 / 384-term list and the node queue, and the walk starts again through the assembly loop -- the same bits."""
+    from gpu_nbody_simulation_amd.engine import FLAG_WALK_PORTABLE
+    rng = np.random.default_rng(n)
+    p = np.concatenate([rng.normal(0, 3e-2, (n // 2, 2)), rng.uniform(-1, 1, (n - n // 2, 2))])
+    m, v = rng.uniform(0.1, 0.5, n), rng.uniform(-1e-7, 1e-7, (n, 2))
+    m[::9] = 1e-16
+    res = []
+    for bpw, flags in ((None, 0), ("64", 0), ("1", 0), (None, FLAG_WALK_PORTABLE)):
+        if bpw is None:
+            monkeypatch.delenv("BH_EXACT_BPW", raising=False)
+        else:
+            monkeypatch.setenv("BH_EXACT_BPW", bpw)
+        with G.BarnesHutEngine(G.BhConfig(capacity=n, theta=theta, max_depth=md, reference_compat=compat, flags=flags)) as e:
+            e.upload(p, v, m)
+            f = e.compute_forces()
+            e.step(3)
+            res.append((f,) + e.download())
+    # (a body of a multi-occupant depth-cap cell can sit exactly on the aggregate: inf * 0 = NaN in the reference too)
+    assert np.isfinite(res[0][0]).mean() > 0.9 and np.nanmax(np.abs(res[0][0])) > 0
+    for other in res[1:]:
+        for x, y in zip(res[0], other):
+            assert np.array_equal(x, y, equal_nan=True)
