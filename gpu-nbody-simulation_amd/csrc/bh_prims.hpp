@@ -141,8 +141,13 @@ __device__ __forceinline__ double wave_bcast63(double v)
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), 63);
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
+// (min / max over the wave as the reference folds its bounds -- xMin = std::min(xMin, x) from +inf, project.cu:544-551 -- : a NaN
+// never wins a comparison there, so it must not win here either.  `(b < a) ? b : a` ignores a NaN that comes IN, but a lane whose OWN
+// value is NaN would keep it, and whether that reaches the result depended on which lane held it: one body gone NaN (a massless
+// body's 0/0 acceleration) could take the next step's root box, and with it every body, along.  Found in round 4 by a random test.)
 __device__ __forceinline__ double wave_min(double v)
 {
+    v = (v <= (double)INFINITY) ? v : (double)INFINITY;
     auto mn = [](double a, double b) { return (b < a) ? b : a; };
     v = mn(v, dpp_mov_self<kDppShr1, 0xF>(v));
     v = mn(v, dpp_mov_self<kDppShr2, 0xF>(v));
@@ -154,6 +159,7 @@ __device__ __forceinline__ double wave_min(double v)
 }
 __device__ __forceinline__ double wave_max(double v)
 {
+    v = (v >= -(double)INFINITY) ? v : -(double)INFINITY;
     auto mx = [](double a, double b) { return (a < b) ? b : a; };
     v = mx(v, dpp_mov_self<kDppShr1, 0xF>(v));
     v = mx(v, dpp_mov_self<kDppShr2, 0xF>(v));

@@ -426,3 +426,74 @@ def test_one_wavefront_per_body_walk_equals_the_cooperative_walk(monkeypatch, n,
     for other in res[1:]:
         for x, y in zip(res[0], other):
             assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_one_wavefront_per_body_walk_on_random_small_trees(monkeypatch):
+    """120 seeded random cases: 1 to 700 bodies, clustered with exact duplicates (many occupants per depth-cap cell), zero and
+    tiny masses, depth caps 1 to 32, theta from 1e-3 to 3, both occupant rules -- the breadth-first walk of small launches
+    against the cooperative walk, forces and two steps BITWISE (NaNs of the reference's own inf * 0 included)."""
+    rng = np.random.default_rng(2024)
+    for case in range(120):
+        n = int(rng.integers(1, 700))
+        md = int(rng.choice([1, 2, 3, 5, 8, 10, 16, 21, 32]))
+        theta = float(10.0 ** rng.uniform(-3, 0.5))
+        compat = bool(rng.integers(0, 2))
+        centres = rng.uniform(-1, 1, (int(rng.integers(1, 6)), 2))
+        p = centres[rng.integers(0, len(centres), n)] + rng.normal(0, 10.0 ** rng.uniform(-6, -1), (n, 2))
+        if n > 4:
+            p[rng.integers(0, n, n // 5)] = p[rng.integers(0, n, n // 5)]          # exact duplicates
+        m = 10.0 ** rng.uniform(-3, 1, n)
+        m[rng.random(n) < 0.1] = 0.0
+        m[rng.random(n) < 0.05] = 1e-16
+        v = rng.normal(0, 1e-6, (n, 2))
+        res = []
+        for bpw in (None, "64"):
+            if bpw is None:
+                monkeypatch.delenv("BH_EXACT_BPW", raising=False)
+            else:
+                monkeypatch.setenv("BH_EXACT_BPW", bpw)
+            # (exact duplicates under a deep cap are chains of 30 nested cells: room for them)
+            with G.BarnesHutEngine(G.BhConfig(capacity=n, theta=theta, max_depth=md, reference_compat=compat,
+                                              node_capacity=140 * n + 4096)) as e:
+                e.upload(p, v, m)
+                f = e.compute_forces()
+                e.step(2)
+                res.append((f,) + e.download())
+        for x, y in zip(res[0], res[1]):
+            assert np.array_equal(x, y, equal_nan=True), (case, n, md, theta, compat)
+
+
+@pytest.mark.parametrize("bpw", [None, "64", "16"])
+@pytest.mark.parametrize("precision", [G.Precision.F64_EXACT, G.Precision.F64])
+def test_a_body_gone_nan_does_not_take_the_root_box_along(monkeypatch, precision, bpw):
+    """A massless body's acceleration is 0 / 0 (project.cu:827): its position is NaN from the first step on.  The reference
+    folds the root box with std::min / std::max from +-inf (project.cu:544-551), which a NaN never wins, so everybody else
+    carries on -- the oracle says so.  The walks' epilogues reduce the new positions over the wave: a lane whose OWN value was
+    NaN kept it, and if that lane was the one the reduction ends in, the next root box was NaN and every body with it (found
+    by the random test above, fixed in wave_min / wave_max).  Three steps against the oracle, NaNs in the same places."""
+    rng = np.random.default_rng(8)
+    n = 700
+    p, v = rng.uniform(-1, 1, (n, 2)), rng.normal(0, 1e-6, (n, 2))
+    m = rng.uniform(0.1, 1.0, n)
+    m[63] = 0.0; m[64 * 5 + 15] = 0.0; m[n - 1] = 0.0; m[128] = 0.0           # the last lane of a wave, of a 16-body wave, ...
+    if bpw is None:
+        monkeypatch.delenv("BH_EXACT_BPW", raising=False)
+    else:
+        monkeypatch.setenv("BH_EXACT_BPW", bpw)
+    pos, vel = p.copy(), v.copy()
+    with G.BarnesHutEngine(G.BhConfig(capacity=n, max_depth=10, precision=precision)) as e:
+        e.upload(p, v, m)
+        for step in range(3):
+            t = O.build_tree(pos, m, 10)
+            _, vel, pos = O.integrate(O.compute_forces(t, pos, m), m, vel, pos)
+            e.step(1)
+            pp, vv = e.download()
+            assert int(np.isnan(pos).any(axis=1).sum()) == 4
+            ok = ~np.isnan(pos).any(axis=1)
+            if precision == G.Precision.F64_EXACT:
+                assert np.array_equal(pp, pos, equal_nan=True) and np.array_equal(vv, vel, equal_nan=True)
+            else:
+                # (the throughput walk sums accelerations, not forces: its massless bodies move on finite orbits; everybody
+                #  else agrees with the oracle, whose massless bodies -- NaN, hence invisible to its tree -- pull nobody)
+                assert np.isfinite(pp).all()
+                assert np.abs(pp[ok] - pos[ok]).max() <= 1e-11 * np.ptp(pos[ok], axis=0).max()
