@@ -187,7 +187,11 @@ const char *bh_build_info(void);
  * bh_upload replaces the three cudaMemcpy H2D of project.cu:943-945 (and, on the caller's
  * side, the arrays filled by loadSimulationDataFromText, project.cu:103-161).
  * bh_download replaces the per-step D2H of positions (project.cu:1010) and additionally
- * returns velocities, which the reference never exposes.  vel may be NULL. */
+ * returns velocities, which the reference never exposes.  vel may be NULL.
+ * Masses: BH_PRECISION_F64_EXACT reproduces the reference bit for bit for POSITIVE masses (however small).  A mass of
+ * exactly 0.0 is accepted, but QuadInsert takes a leaf whose mass is 0.0 for empty (project.cu:395-397): a massless
+ * body is overwritten by a later arrival and subdivides an earlier one, an insertion-order-dependent tree that
+ * this build does not reproduce -- here a massless body occupies its leaf like any other (and pulls nobody). */
 int bh_upload(bh_ctx *ctx, const double *pos, const double *vel, const double *mass, int64_t n);
 int bh_download(bh_ctx *ctx, double *pos, double *vel);
 
