@@ -159,3 +159,37 @@ def test_asm_walk_equals_the_portable_walk(kind, n, md, compat, theta):
     for other in res[1:]:
         for x, y in zip(res[0], other):
             assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_random_small_systems_against_the_oracle():
+    """60 seeded random systems (2 to 600 bodies; clusters, masses 1e-16 to 100, depth caps 2 to 32, theta 0.05 to 2, both
+    occupant rules): the throughput walk's forces within 1e-12 of the oracle's + the forward rounding model of the
+    coordinate differences (1e-13 x WalkDiag.coord, the force goes with d^-3: a body that shares a depth-cap cell with a 1e-16-mass neighbour meets an
+    aggregate 1e-21 away from itself, and its "force" of 1e20 is rounding noise in the reference as well), with the oracle's
+    per-body interaction counts -- both the hand-written loop and its counting statement."""
+    rng = np.random.default_rng(91)
+    for case in range(60):
+        n = int(rng.integers(2, 600))
+        md = int(rng.choice([2, 4, 7, 10, 15, 21, 32]))
+        theta = float(10.0 ** rng.uniform(-1.3, 0.3))
+        compat = bool(rng.integers(0, 2))
+        centres = rng.uniform(-1, 1, (int(rng.integers(1, 5)), 2))
+        p = centres[rng.integers(0, len(centres), n)] + rng.normal(0, 10.0 ** rng.uniform(-4, -1), (n, 2))
+        m = 10.0 ** rng.uniform(-4, 2, n)
+        m[rng.random(n) < 0.08] = 1e-16
+        v = np.zeros((n, 2))
+        # (pos_rounded: the model counts leaves too -- a depth-cap aggregate is a leaf of the reference's tree)
+        d = O.compute_forces_diag(O.build_tree(p, m, md), p, m, theta=theta, compat_self_skip=compat, pos_rounded=True)
+        fo = d.forces
+        # (a term whose distance is 1e-8 of the coordinates it is the difference of -- a body against the depth-cap aggregate
+        #  it is itself most of -- has no significant digits in the reference either: those bodies are not compared)
+        ok = np.isfinite(fo).all(axis=1) & np.isfinite(d.coord) & (d.coord < 1e8 * d.abs_sum)
+        for flags in (0, FLAG_WALK_STATS):
+            with engine(n, theta=theta, max_depth=md, reference_compat=compat, flags=flags, node_capacity=140 * n + 4096) as e:
+                e.upload(p, v, m)
+                f = e.compute_forces()
+                if flags:
+                    assert np.array_equal(e.interaction_counts()[ok], d.counts[ok]), (case, n, md, theta, compat)
+            err = np.linalg.norm(f[ok] - fo[ok], axis=1)
+            tol = TOL * np.linalg.norm(fo[ok], axis=1) + 1e-13 * d.coord[ok]
+            assert (err <= tol).all(), (case, n, md, theta, compat, float((err / np.maximum(tol, 1e-300)).max()))
