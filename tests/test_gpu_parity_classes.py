@@ -61,3 +61,33 @@ def test_counting_walk_and_product_walk_are_the_same_walk():
             e.compute_forces()
             acc.append(e.accelerations())
     assert np.array_equal(acc[0], acc[1]) and np.array_equal(acc[0], acc[2])
+
+
+def test_random_systems_by_class():
+    """40 seeded random systems in fp32 (64 to 40,000 bodies -- the one-wave walk, and the level-synchronous walk over 2, 4 and 8
+    waves per group, whichever the launch size picks; 1 to 4 clusters of widths 1e-3 to 0.3; masses over four decades;
+    theta 0.2 to 1.2): every body whose walk meets no borderline criterion accepts EXACTLY the oracle's node set (per-body
+    counts), stays inside the forward rounding bound, and the borderline bodies inside their flip budget."""
+    rng = np.random.default_rng(314)
+    for case in range(40):
+        n = int(2 ** rng.uniform(6, 15.3))
+        theta = float(rng.uniform(0.2, 1.2))
+        centres = rng.uniform(-1, 1, (int(rng.integers(1, 5)), 2))
+        p = (centres[rng.integers(0, len(centres), n)] + rng.normal(0, 10.0 ** rng.uniform(-3, -0.5), (n, 2))).astype(np.float32).astype(np.float64)
+        m = (10.0 ** rng.uniform(-2, 2, n)).astype(np.float32).astype(np.float64)
+        v = np.zeros((n, 2))
+        with G.BarnesHutEngine(G.BhConfig(capacity=n, theta=theta, max_depth=21, precision=G.Precision.F32,
+                                          reference_compat=False, flags=FLAG_WALK_STATS)) as e:
+            e.upload(p, v, m)
+            e.compute_forces()
+            a = e.accelerations()
+            cnt = e.interaction_counts()
+            st = e.stats()
+        assert int(cnt.sum()) == st.interactions, (case, n, theta)
+        rep = PC.classify(a, cnt, m, p, theta, n)
+        assert rep.clean_count_mismatches == 0, (case, n, theta, rep)
+        assert rep.clean_model_max <= PC.MODEL_MAX, (case, n, theta, rep)
+        assert rep.borderline_excess_max <= 5e-2 and rep.nonfinite == 0, (case, n, theta, rep)
+        # (no fixed relative tolerance: a cluster 1e-3 wide at distance 1 from the origin keeps three digits fewer of its
+        #  coordinate differences in fp32 than one at the origin -- the rounding bound above prices exactly that)
+        assert rep.clean_fraction >= 0.9, (case, n, theta, rep)
