@@ -681,6 +681,12 @@ def main():
                 leg, _, _ = timed_leg(G, cfg_e, me, pe, ve, ks, 2)
                 leg["roofline"] = walk_roofline(G, cfg_e, me, pe, ve, leg["walk_ms"], FLAG_WALK_STATS, kind="exact")
                 leg["roofline"]["kernel"] = "walk_exact_kernel"
+                if nn <= 12288:
+                    # (launches this small walk with one wavefront per body, breadth-first -- csrc/bh_walk_exact.hpp,
+                    # walk_exact_bfs_kernel; the counters above are the cooperative walk's, the issue model is not this kernel's)
+                    leg["roofline"]["kernel"] = "walk_exact_bfs_kernel"
+                    leg["roofline"]["issue_frac"] = None
+                    leg["roofline"].pop("issue", None)
                 if tag == "C3" and nn == 1 << 20 and kind == "plummer":
                     leg["roofline"].update(committed_traffic("EXACT"))       # (profiles/r04_exact: this workload)
                 leg["step_roofline"] = step_roofline(leg["ms_per_step"], nn, leg["roofline"]["u64_nodes_per_body"],
