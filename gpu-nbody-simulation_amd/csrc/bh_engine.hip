@@ -587,7 +587,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
             auto args = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), 0, c->stream, c->gd, c->ld, c->perm, (double2 *)c->pos,
                                    (double2 *)c->vel, (const double *)c->mass, (double2 *)c->force, lo, hi, c->cfg.G, c->cfg.dt,
-                                   integrate ? 1 : 0, c->ctr, partial, slots);
+                                   integrate ? 1 : 0, c->ctr, partial, slots, c->box);
                 c->walk_launches += 1;
             };
             const bool big = cnt > 4096;                         // (more interactions per body in larger trees: 384 terms per walk -- 52 KB of LDS per workgroup, three per CU; 512 would leave two)
@@ -606,7 +606,7 @@ int enqueue_walk(bh_ctx *c, bool integrate, bool to_sorted, int part = 0)
                 hipLaunchKernelGGL(kern, dim3(blocks_for(phi - plo, per_block)), dim3(kBlock), 0, c->stream, c->gd, c->ld, c->perm,
                                    (double2 *)c->pos, (double2 *)c->vel, (const double *)c->mass,
                                    (double2 *)c->force, plo, phi, c->cfg.theta, c->cfg.G, c->cfg.dt,
-                                   integrate ? 1 : 0, c->ctr, pp, slots, bpw);
+                                   integrate ? 1 : 0, c->ctr, pp, slots, bpw, c->box);
                 c->walk_launches += 1;
             };
             // (the node kernel stored what this walk reads in the size slot: exact thresholds, or the sizes for the portable

@@ -12,9 +12,10 @@
 // nodes its own walk would pop, adds its terms in exactly the reference's order: same fp64
 // operations, same order, same bits.  Node loads are wave-uniform (scalar loads), so a visit
 // costs 40 bytes per wave instead of 64 divergent gathers.
-// Three statements of the walk, bit-identical on every input (tests/test_gpu_exact.py): the hand-written gfx950 loop
-// (walk_exact_asm: the product), the C++ loop with the same arithmetic (the counting variant), and the walk written as the
-// reference writes it -- sqrt, size / d < theta, three divisions (BH_FLAG_WALK_PORTABLE).
+// Four statements of the walk, bit-identical on every input (tests/test_gpu_exact.py): the hand-written gfx950 loop
+// (walk_exact_asm: the product from ~12k bodies up), the C++ loop with the same arithmetic (the counting variant), the walk
+// written as the reference writes it -- sqrt, size / d < theta, three divisions (BH_FLAG_WALK_PORTABLE) --, and for small
+// launches one wavefront per BODY, breadth-first, with the terms added in DFS-key order (walk_exact_bfs_kernel, at the end).
 #pragma once
 
 #include "bh_tree.hpp"
@@ -32,7 +33,8 @@ extern "C" __device__ int exact_writelane_i32(int value, int lane, int old) __as
 //   v_add                d2                           s_cmp + branch: leaf (occupant test by v_cmpx_ne_u32, out of line)
 //   v_cmpx_le_f64        thr <= d2: EXEC := the lanes that accept; s_andn2: the lanes that open
 //   s_cbranch_execz      nobody takes the node
-//   v_cmp x3, s_and x3   operand ranges of the takers (dx^2, dy^2 >= 2^-400, d2 <= 2^400, G m_i in 2^+-150); s_andn2 + branch
+//   v_cmp x2, s_and x2   operand ranges of the takers (dx^2, dy^2 >= 2^-400, G m_i in 2^+-150; d2 <= 2^400 follows from the root
+//                        box, checked once per launch: lanes_safe is empty when an extent exceeds 2^199); s_andn2 + branch
 //   36 x fp64            sqrt(d2) (v_rsq_f64, one coupled Newton step, two residual corrections), 1 / d2 and 1 / d
 //                        (v_rcp_f64 + two Newton steps each), three quotients q + r (a - b q), two products, two sums --
 //                        the instruction sequences the compiler expands sqrt() and `/` to, the three chains interleaved
@@ -174,8 +176,6 @@ extern "C" __device__ int exact_writelane_i32(int value, int lane, int old) __as
     "v_cmp_ge_f64 vcc, " BHX_TA ", %[tiny2]\n"                                                      \
     "v_cmp_ge_f64 s[44:45], " BHX_TB ", %[tiny2]\n"                                                 \
     "s_and_b64 vcc, vcc, s[44:45]\n"                                                                \
-    "v_cmp_le_f64 s[44:45], " BHX_D2 ", %[huge]\n"                                                  \
-    "s_and_b64 vcc, vcc, s[44:45]\n"                                                                \
     "s_and_b64 vcc, vcc, %[lsafe]\n"                                                                \
     "s_andn2_b64 s[44:45], exec, vcc\n"                                                             \
     "s_cbranch_scc1 Lgen" T "_%=\n"                                                                 \
@@ -264,7 +264,7 @@ extern "C" __device__ int exact_writelane_i32(int value, int lane, int old) __as
 #define BHX_OPERANDS                                                                                \
     : [fx] "+v"(fx), [fy] "+v"(fy)                                                                  \
     : [px] "v"(px), [py] "v"(py), [gm] "v"(gm), [body] "v"(body), [alt] "v"(alt), [gd] "s"(gd), [ld] "s"(ld),           \
-      [tiny2] "s"(tiny2), [huge] "s"(huge), [eps] "s"(eps), [lsafe] "s"(lanes_safe), [quad] "s"(quad), [live] "s"(live) \
+      [tiny2] "s"(tiny2), [eps] "s"(eps), [lsafe] "s"(lanes_safe), [quad] "s"(quad), [live] "s"(live)                    \
     : BHX_GUARD_CLOBBER                                                                             \
       "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39",   \
       "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s64", "s65", "s66", "s67", "s70", "s71",   \
@@ -275,13 +275,15 @@ extern "C" __device__ int exact_writelane_i32(int value, int lane, int old) __as
 // Walks the subtree below quad `quad` (node id of its first sibling) for the lanes in `live`, visiting children 3,2,1,0 and
 // every subtree before the next sibling: each lane's terms are added in the reference's order (project.cu:662-668).
 // gd / ld: the node and link arrays; byte offsets are 32-bit (the caller checks node_cap * 32 < 4 GiB).
+// lanes_safe: the lanes whose G m_i is inside 2^+-150 -- and NONE unless both extents of the root box are <= 2^199 (every body and
+// every centre of mass lies inside it, so dx^2 + dy^2 <= 2^399: the one range test this loop leaves to its caller).
 template <bool COMPAT>
 __device__ __forceinline__ void walk_exact_asm(const char __attribute__((address_space(4))) *gd,
                                                const char __attribute__((address_space(4))) *ld, int32_t quad, uint64_t live,
                                                uint64_t lanes_safe, double px, double py, double gm, int32_t body, int32_t alt,
                                                double &fx, double &fy)
 {
-    const double tiny2 = 0x1p-400, huge = 0x1p400, eps = 1e-15;
+    const double tiny2 = 0x1p-400, eps = 1e-15;
     if constexpr (COMPAT) asm volatile(BHX_LOOP(BHX_COMPAT_ON) BHX_OPERANDS);
     else asm volatile(BHX_LOOP(BHX_COMPAT_OFF) BHX_OPERANDS);
 }
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
     const NodeD *__restrict__ gd, const LinkD *__restrict__ ld, const uint32_t *__restrict__ perm,
     double2 *__restrict__ pos, double2 *__restrict__ vel, const double *__restrict__ mass,
     double2 *__restrict__ force_out, int64_t lo, int64_t hi, double theta, double G, double dt,
-    int integrate, TreeCounters *ctr, double *__restrict__ partial, double *slots, int bpw)
+    int integrate, TreeCounters *ctr, double *__restrict__ partial, double *slots, int bpw, const double *__restrict__ box)
 {
     // bpw: bodies per wavefront, a power of two <= 64 (lanes bpw .. 63 idle).  A wave's walk is ONE dependent chain over the
     // union of its lanes' walks; a launch of few bodies leaves the GPU empty however it is cut, so the engine gives every
@@ -324,7 +326,9 @@ __global__ __launch_bounds__(kBlock) void walk_exact_kernel(
     // exponents of numerator and denominator differ by >= 768 or either is within ~2^53 of the ends of the format)
     constexpr double kLaneLo = 0x1p-150, kLaneHi = 0x1p150, kTiny = 0x1p-200, kHuge = 0x1p400;
     const bool lane_safe = THR && fabs(Gm) >= kLaneLo && fabs(Gm) <= kLaneHi;
-    const uint64_t lanes_safe = __ballot(lane_safe);
+    // (the root box bounds every |dx|, |dy| of this launch: with extents <= 2^199 no d2 exceeds 2^399)
+    const bool box_ok = ASM && (box[1] - box[0]) <= 0x1p199 && (box[3] - box[2]) <= 0x1p199;
+    const uint64_t lanes_safe = __ballot(lane_safe && box_ok);
     const int32_t body_lo = (int32_t)body, body_alt = (int32_t)(-body - 2);     // (bodies < 2^31: bh_create)
     double fx = 0.0, fy = 0.0;
     unsigned long long n_vis = 0, n_int = 0, n_wave = 0, n_acc = 0;
@@ -601,7 +605,7 @@ __global__ __launch_bounds__(kBlock) void walk_exact_bfs_kernel(
     const NodeD *__restrict__ gd, const LinkD *__restrict__ ld, const uint32_t *__restrict__ perm,
     double2 *__restrict__ pos, double2 *__restrict__ vel, const double *__restrict__ mass,
     double2 *__restrict__ force_out, int64_t lo, int64_t hi, double G, double dt, int integrate, TreeCounters *ctr,
-    double *__restrict__ partial, double *slots)
+    double *__restrict__ partial, double *slots, const double *__restrict__ box)
 {
     __shared__ uint64_t s_meta[kWavesPerBlock][kBfsQueue];       // node id | depth << 32
     __shared__ uint64_t s_qkey[kWavesPerBlock][kBfsQueue];
@@ -611,6 +615,7 @@ __global__ __launch_bounds__(kBlock) void walk_exact_bfs_kernel(
     if (ctr->overflow) return;
     const int lane = lane_id(), w = wave_id();
     constexpr double kLaneLo = 0x1p-150, kLaneHi = 0x1p150, kTiny = 0x1p-200, kHuge = 0x1p400;
+    const bool box_ok = (box[1] - box[0]) <= 0x1p199 && (box[3] - box[2]) <= 0x1p199;        // (walk_exact_asm's precondition)
     // body k of this wave: sorted index lo + (k * gridDim.x + blockIdx.x) * 4 + w; its new position stays in lane k for the
     // workgroup's bounds record
     double npx = 0.0, npy = 0.0;
@@ -739,7 +744,7 @@ __global__ __launch_bounds__(kBlock) void walk_exact_bfs_kernel(
 #pragma clang diagnostic ignored "-Wold-style-cast"
                 walk_exact_asm<COMPAT>((const char __attribute__((address_space(4))) *)gd,
                                        (const char __attribute__((address_space(4))) *)ld,
-                                       __builtin_amdgcn_readfirstlane(child), 1ull, __ballot(lane_safe) & 1ull, p.x, p.y, Gm,
+                                       __builtin_amdgcn_readfirstlane(child), 1ull, __ballot(lane_safe && box_ok) & 1ull, p.x, p.y, Gm,
                                        (int32_t)body, COMPAT ? (int32_t)(-body - 2) : (int32_t)body, fx, fy);
 #pragma clang diagnostic pop
             }
