@@ -55,10 +55,10 @@ F64_CYCLES_PER_ACCEPTED = 17.0 + 11 * 5.3
 F64_CYCLES_PER_QUAD = 2.5 * 4.1 + 2.5 * 4.2
 F64_NODE_BYTES, F64_BODY_BYTES = 40, 92
 # BH_PRECISION_F64_EXACT walk (csrc/bh_walk_exact.hpp, walk_exact_asm), same calibrated costs.  Per evaluated (non-empty)
-# node: dx, dy, dx^2, dy^2, d2 + the threshold compare; per node some lane takes a term from: three range compares, G m_i m,
+# node: dx, dy, dx^2, dy^2, d2 + the threshold compare; per node some lane takes a term from: two range compares, G m_i m,
 # v_rsq_f64 + two v_rcp_f64, 30 more fp64 instructions (Newton steps, quotient corrections, products), two sums.
 EXACT_CYCLES_PER_NODE = 6 * 5.3
-EXACT_CYCLES_PER_ACCEPTED = 3 * 17.0 + (3 + 1 + 30 + 2) * 5.3
+EXACT_CYCLES_PER_ACCEPTED = 3 * 17.0 + (2 + 1 + 30 + 2) * 5.3
 # algorithmic bytes of one whole step per body, fp32 state -- fixed pipeline ~270 B + walk 12 + 20 U64 + 8
 SURVEY_PIPELINE_BYTES, SURVEY_WALK_FIXED_BYTES = 270, 20
 
