@@ -535,3 +535,35 @@ def test_random_small_systems_against_the_oracle():
                 e.step(1)
                 pp, vv = e.download()
                 assert np.array_equal(pp, pos, equal_nan=True) and np.array_equal(vv, vel, equal_nan=True), (case, step, n, md, theta, compat)
+
+
+def test_random_call_sequences_on_one_context_against_the_oracle():
+    """One context, 14 uploads of different sizes in random order (1 ... 20,000 bodies: across the one-bucket sort's 4,096,
+    the one-wavefront-per-body walk's 12,288 and back), each followed by a random mix of bh_step(k), bh_compute_forces and
+    tree exports: whatever the previous upload left behind (splitters, bounds records, their count, the sorted order), the
+    state after every call is the oracle's, BITWISE."""
+    from gpu_nbody_simulation_amd import initial_conditions as IC
+    rng = np.random.default_rng(4242)
+    sizes = [1, 50, 1000, 4096, 4097, 5000, 12288, 12289, 20000, 700, 8192, 3, 16384, 1024]
+    rng.shuffle(sizes)
+    with G.BarnesHutEngine(G.BhConfig(capacity=20000, max_depth=10, node_capacity=200000)) as e:
+        for n in sizes:
+            m, p, v = IC.make("plummer" if rng.random() < 0.5 else "uniform", int(n), int(rng.integers(1, 100)), quasi_static=True)
+            pos, vel = p.copy(), v.copy()
+            e.upload(p, v, m)
+            for _ in range(int(rng.integers(1, 4))):
+                op = rng.integers(0, 3)
+                if op == 0:
+                    k = int(rng.integers(1, 4))
+                    e.step(k)
+                    for _s in range(k):
+                        t = O.build_tree(pos, m, 10)
+                        _, vel, pos = O.integrate(O.compute_forces(t, pos, m), m, vel, pos)
+                elif op == 1:
+                    f = e.compute_forces()
+                    assert np.array_equal(f, O.compute_forces(O.build_tree(pos, m, 10), pos, m), equal_nan=True), n
+                else:
+                    e.build_tree()
+                    _same_tree(e, O.build_tree(pos, m, 10))
+                pp, vv = e.download()
+                assert np.array_equal(pp, pos, equal_nan=True) and np.array_equal(vv, vel, equal_nan=True), (n, op)

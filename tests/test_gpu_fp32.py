@@ -647,3 +647,38 @@ def test_theta_and_depth_cap_matrix_against_the_oracle(theta, max_depth):
     r = rel_err(a[ok], ref[ok])
     assert np.median(r) <= 5e-6, np.median(r)
     assert np.quantile(r, 0.9) <= 1e-3, np.quantile(r, 0.9)
+
+
+@pytest.mark.parametrize("precision", ["f32", "mixed"])
+def test_random_call_sequences_on_one_context_equal_fresh_contexts(precision):
+    """One context, 14 uploads of different sizes in random order (1 ... 300,000 bodies: across the one-bucket sort's 4,096,
+    the split walks' launch-size thresholds, the 256-bucket sort's first and later builds), each followed by a random mix of
+    bh_step(k) and bh_compute_forces: whatever the previous upload left behind (splitters, sorted copies, bounds records,
+    the re-ordering counter), every result is BITWISE that of a fresh context given the same calls."""
+    prec = {"f32": G.Precision.F32, "mixed": G.Precision.MIXED}[precision]
+    rng = np.random.default_rng(777)
+    sizes = [1, 64, 1000, 4096, 4097, 20000, 65536, 70000, 200000, 300000, 130, 8192, 2, 131072]
+    rng.shuffle(sizes)
+    with engine(300000, max_depth=21, reference_compat=False, precision=prec) as shared:
+        for n in sizes:
+            m, p, v = IC.make("plummer" if rng.random() < 0.5 else "uniform", int(n), int(rng.integers(1, 100)), quasi_static=True, drift_cells=0.5)
+            ops = [(int(rng.integers(0, 2)), int(rng.integers(1, 20))) for _ in range(int(rng.integers(1, 4)))]
+            out = []
+            for ctx in (shared, None):
+                e = ctx if ctx is not None else engine(int(n), max_depth=21, reference_compat=False, precision=prec).__enter__()
+                try:
+                    e.upload(p, v, m)
+                    res = []
+                    for op, k in ops:
+                        if op == 0:
+                            e.step(k)
+                        else:
+                            res.append(e.compute_forces())
+                        res.extend(e.download())
+                    out.append(res)
+                finally:
+                    if ctx is None:
+                        e.__exit__(None, None, None)
+            assert len(out[0]) == len(out[1])
+            for x, y in zip(out[0], out[1]):
+                assert np.array_equal(x, y, equal_nan=True), (n, ops)
